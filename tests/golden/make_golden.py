@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory by running the REFERENCE itself.
+
+Runs only in the build container (needs /root/reference, which never travels to the
+GPU box).  It imports the reference's own `main.XVectorModel` / `tdnn_layer` -- after
+registering empty stand-in modules for the third-party packages that are not
+installed here (pytorch_lightning, torchmetrics, speechbrain, resampy,
+python_speech_features, seaborn, tensorboard) -- loads deterministic weights produced
+by this repo's generator (synth.py, seed-addressed) via load_state_dict, and records
+the reference's outputs.  Nothing of the reference is copied: fixtures hold inputs
+seeds and expected output arrays only.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+Fixture groups:
+  g1_time_context.npz  get_time_context known answers (extra/time_context_test.py cases
+                       + the tdnn_layer.py:46-53 docstring case)
+  g2_layers.npz        per-layer TdnnLayer outputs, full-width model, B=3 T=50
+                       (selected frames + whole-tensor sums)
+  g3_stat_pool.npz     stat_pool on [4,286,1500] and n in {2,3} edge sizes
+  g4_full.npz          extract_x_vec (layer 6, 7) and forward logits, B in {1,8}, T in {299,300}
+  g5_ragged.npz        lengths {200,333,1000} each run at batch=1 un-padded
+  g6_tiny.npz          reduced-width model with its weights stored in full (+ no-BN variant)
+  g7_caller.npz        test_step/test_epoch_end I/O: row order + fp32->float64 widening
+"""
+import importlib
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.dont_write_bytecode = True
+
+
+# --------------------------------------------------------------------------- stand-ins
+class _Anything:
+    def __init__(self, *a, **k):
+        pass
+
+    def __call__(self, *a, **k):
+        return _Anything()
+
+    def __getattr__(self, name):
+        return _Anything()
+
+
+class _StubModule(types.ModuleType):
+    __path__ = []  # behave like a package so "import a.b.c" works
+    __all__ = []   # "from stub import *" imports nothing
+
+    def __getattr__(self, name):
+        if name.startswith("__"):
+            raise AttributeError(name)
+        return _Anything
+
+
+class _LightningModule(nn.Module):
+    def save_hyperparameters(self, *a, **k):
+        pass
+
+    def log(self, *a, **k):
+        pass
+
+
+def install_stubs():
+    names = ["pytorch_lightning", "pytorch_lightning.loggers", "pytorch_lightning.callbacks",
+             "pytorch_lightning.callbacks.early_stopping", "torchmetrics", "speechbrain",
+             "speechbrain.processing", "speechbrain.processing.PLDA_LDA", "speechbrain.utils",
+             "speechbrain.utils.metric_stats", "resampy", "python_speech_features", "seaborn"]
+    for mod in ("torch.utils.tensorboard", "matplotlib", "matplotlib.pyplot", "sklearn",
+                "sklearn.manifold", "sklearn.model_selection", "pandas", "scipy.io", "scipy.signal"):
+        try:
+            importlib.import_module(mod)
+        except Exception:
+            names.append(mod)
+    for n in names:
+        m = _StubModule(n)
+        sys.modules[n] = m
+        if "." in n:
+            parent, child = n.rsplit(".", 1)
+            if parent in sys.modules:
+                setattr(sys.modules[parent], child, m)
+    sys.modules["pytorch_lightning"].LightningModule = _LightningModule
+
+
+def load_pkg():
+    sys.path.insert(0, REPO)
+    return importlib.import_module("xvector_amd")
+
+
+# --------------------------------------------------------------------------- helpers
+def to_t(sd):
+    return {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}
+
+
+def ref_model(main, sd, **kw):
+    m = main.XVectorModel(**kw)
+    missing = m.load_state_dict(to_t(sd), strict=False)
+    # only non-hot-path state (torchmetrics etc.) may be absent
+    assert not [k for k in missing.missing_keys if not k.startswith(("accuracy", "dataset"))], missing
+    assert not missing.unexpected_keys, missing
+    return m.eval()
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **arrays)
+    print(f"wrote {name}: {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def main_():
+    assert os.path.isdir(REF), "reference not present: fixtures can only be generated in the build container"
+    install_stubs()
+    sys.path.insert(0, REF)
+    tdnn = importlib.import_module("tdnn_layer")
+    main = importlib.import_module("main")
+    synth = load_pkg().synth
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+
+    with torch.no_grad():
+        # ---- G1: get_time_context known answers --------------------------------
+        rows = [list(range(1, 16))]
+        for s in (3, 6, 9, 12):
+            rows.append([(v + s - 1) % 15 + 1 for v in range(1, 16)])
+        x15 = torch.tensor(rows, dtype=torch.float32).unsqueeze(-1)        # [5,15,1]
+        g1 = {"x15": x15.numpy()}
+        for i, ctx in enumerate([[-2, -1, 0, 1, 2], [-2, 2], [-4, -2, 0, 2, 4], list(range(-5, 6))]):
+            g1[f"ctx{i}"] = np.array(ctx, dtype=np.int32)
+            g1[f"out{i}"] = torch.cat(tdnn.get_time_context(x15, ctx), 2).numpy()
+        xdoc = torch.tensor([[[1., 2.], [3., 4.], [5., 6.], [7., 8.], [9., 0.]]])
+        g1["xdoc"] = xdoc.numpy()
+        g1["outdoc"] = torch.cat(tdnn.get_time_context(xdoc, [-1, 0, 1]), 2).numpy()
+        save("g1_time_context.npz", **g1)
+
+        # ---- full-width model, seed 42 -----------------------------------------
+        sd = synth.make_state_dict(seed=42)
+        model6 = ref_model(main, sd)
+        model7 = ref_model(main, sd, x_vec_extract_layer=7)
+
+        # ---- G2: per-layer outputs ---------------------------------------------
+        x = torch.from_numpy(synth.make_mfcc(3, 50, seed=7))
+        g2 = {"seed_w": 42, "seed_x": 7, "B": 3, "T": 50}
+        h = x
+        for i, layer in enumerate(model6.time_context_layers):
+            h = layer(h)
+            tt = sorted({0, 1, h.shape[1] // 2, h.shape[1] - 1})
+            g2[f"l{i}_frames"] = np.array(tt, dtype=np.int32)
+            g2[f"l{i}_rows"] = h[:, tt, :].numpy()
+            g2[f"l{i}_shape"] = np.array(h.shape, dtype=np.int32)
+            g2[f"l{i}_sum"] = h.double().sum(dim=(0, 1)).numpy()          # per-channel sums, all frames
+        save("g2_layers.npz", **g2)
+
+        # ---- G3: stat_pool -----------------------------------------------------
+        rng = np.random.default_rng(11)
+        xp = torch.from_numpy((rng.standard_normal((4, 286, 1500)) * 0.7 + 1.3).astype(np.float32))
+        g3 = {"seed": 11, "scale": 0.7, "shift": 1.3, "pool_286": model6.stat_pool(xp).numpy()}
+        for n in (2, 3):
+            g3[f"pool_{n}"] = model6.stat_pool(xp[:, :n, :64]).numpy()
+        save("g3_stat_pool.npz", **g3)
+
+        # ---- G4: full path -----------------------------------------------------
+        g4 = {"seed_w": 42}
+        for B, T, sx in ((1, 299, 100), (8, 299, 101), (1, 300, 102), (8, 300, 103)):
+            x = torch.from_numpy(synth.make_mfcc(B, T, seed=sx))
+            key = f"B{B}_T{T}"
+            g4[key + "_seed_x"] = sx
+            g4[key + "_xvec6"] = model6.extract_x_vec(x).numpy()
+            g4[key + "_xvec7"] = model7.extract_x_vec(x).numpy()
+            g4[key + "_logits"] = model6(x).numpy()
+        save("g4_full.npz", **g4)
+
+        # ---- G5: ragged semantics (per-utterance, un-padded, batch=1) ----------
+        lens = [200, 333, 1000]
+        xr = synth.make_mfcc(3, 1000, seed=55)
+        g5 = {"seed_w": 42, "seed_x": 55, "lengths": np.array(lens, dtype=np.int32)}
+        g5["xvec6"] = np.concatenate(
+            [model6.extract_x_vec(torch.from_numpy(xr[i:i + 1, :n])).numpy() for i, n in enumerate(lens)])
+        g5["logits"] = np.concatenate(
+            [model6(torch.from_numpy(xr[i:i + 1, :n])).numpy() for i, n in enumerate(lens)])
+        save("g5_ragged.npz", **g5)
+
+        # ---- G6: tiny self-contained model (weights stored) ---------------------
+        kw = dict(input_size=24, hidden_size=32, num_classes=10, x_vector_size=16)
+        g6 = {}
+        for tag, bn in (("bn", True), ("nobn", False)):
+            sdt = synth.make_state_dict(seed=5, batch_norm=bn, **kw)
+            mt = ref_model(main, sdt, batch_norm=bn, **kw)
+            mt7 = ref_model(main, sdt, batch_norm=bn, x_vec_extract_layer=7, **kw)
+            xt = torch.from_numpy(synth.make_mfcc(4, 40, seed=9))
+            if bn:      # self-contained: weights stored in full; the no-BN twin regenerates from its seed
+                for k, v in sdt.items():
+                    g6[f"{tag}/w/{k}"] = v
+            g6[f"{tag}/seed_w"] = 5
+            g6[f"{tag}/x"] = xt.numpy()
+            g6[f"{tag}/xvec6"] = mt.extract_x_vec(xt).numpy()
+            g6[f"{tag}/xvec7"] = mt7.extract_x_vec(xt).numpy()
+            g6[f"{tag}/logits"] = mt(xt).numpy()
+            fr = mt.time_context_layers(xt)
+            g6[f"{tag}/frames_t"] = np.array([0, 13, 25], dtype=np.int32)
+            g6[f"{tag}/frames"] = fr[:, [0, 13, 25], :].numpy()
+            g6[f"{tag}/frames_sum"] = fr.double().sum(dim=(0, 1)).numpy()
+        save("g6_tiny.npz", **g6)
+
+        # ---- G7: caller contract (main.py:135-146) ------------------------------
+        main.x_vector = []
+        xs = torch.from_numpy(synth.make_mfcc(5, 299, seed=77)).double()    # loader hands float64
+        labels = torch.tensor([3, 1, 4, 1, 5])
+        ids = ["id10001/a/0", "id10002/b/1", "id10003/c/2", "id10004/d/3", "id10005/e/4"]
+        outs = model6.test_step((xs, labels, ids), 0)
+        model6.test_epoch_end([outs])
+        g7 = {"seed_w": 42, "seed_x": 77, "labels": labels.numpy(),
+              "ids": np.array(ids), "out_ids": np.array([r[0] for r in main.x_vector]),
+              "out_labels": np.array([r[1] for r in main.x_vector], dtype=np.int64),
+              "out_vecs": np.stack([r[2] for r in main.x_vector])}
+        assert g7["out_vecs"].dtype == np.float64
+        save("g7_caller.npz", **g7)
+
+
+if __name__ == "__main__":
+    main_()

@@ -1,0 +1,133 @@
+/* xvec_hip.h -- C ABI of libxvec_hip.so: the MI355X (gfx950) x-vector extraction path.
+ *
+ * The reference (TorbenHellriegel/Speaker-Recognition-x-vectors) has no FFI, plugin or
+ * operator interface: its boundary for this path is the Python method surface of
+ * XVectorModel (reference main.py:23-94).  The entry points below are what a ctypes
+ * binding of that surface needs (INTEGRATION.md shows the binding); each comment names
+ * the reference code the entry point replaces.
+ *
+ * Conventions
+ *   - every tensor pointer is a DEVICE pointer (HIP) unless the name ends in _host;
+ *   - tensors are contiguous, batch-first, time-major, channels-last, fp32 -- exactly the
+ *     [B,T,C] layout the reference feeds (main.py:99,137);
+ *   - all work is enqueued on the caller's stream and is asynchronous w.r.t. the host;
+ *     nothing allocates device memory after xvec_create;
+ *   - every function returns XVEC_OK (0) or an error code and never throws; the message
+ *     for the last error on the calling thread is available from xvec_last_error();
+ *   - one handle per device; distinct handles may be used from distinct threads.
+ */
+#ifndef XVEC_HIP_H
+#define XVEC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct xvec_handle xvec_handle;
+typedef void* xvec_stream; /* hipStream_t */
+
+enum { XVEC_OK = 0, XVEC_ERR_ARG = 1, XVEC_ERR_HIP = 2, XVEC_ERR_STATE = 3, XVEC_ERR_WORKSPACE = 4 };
+
+/* arithmetic of the frame-level stack (accumulation, pooling and the segment-level
+ * affines are fp32 in both) */
+enum { XVEC_F32 = 0, XVEC_BF16 = 1 };
+
+/* what xvec_forward returns */
+enum {
+    XVEC_MODE_LOGITS = 0, /* XVectorModel.forward        main.py:66-75  -> [B,num_classes] */
+    XVEC_MODE_XVEC6 = 6,  /* extract_x_vec, layer 6      main.py:86-87  -> [B,x_vector_size] */
+    XVEC_MODE_XVEC7 = 7   /* extract_x_vec, layer 7      main.py:88-90  -> [B,x_vector_size] */
+};
+
+/* which segment-level affine (main.py:45-47) */
+enum { XVEC_SEG6 = 6, XVEC_SEG7 = 7, XVEC_OUTPUT = 8 };
+
+#define XVEC_NUM_TDNN 5        /* main.py:38-44 */
+#define XVEC_POOL_CHANNELS 1500 /* main.py:43 (hard-coded in the reference) */
+#define XVEC_TOTAL_CONTEXT 14   /* frames consumed by the valid convolutions */
+#define XVEC_MAX_TIMINGS 16
+
+/* XVectorModel.__init__ shape arguments (main.py:24-34; defaults config.py:4-12) */
+typedef struct {
+    int32_t input_size;    /* 24   */
+    int32_t hidden_size;   /* 512  */
+    int32_t num_classes;   /* 1211 */
+    int32_t x_vector_size; /* 512  */
+    int32_t batch_norm;    /* 1: TdnnLayer has BatchNorm1d after the ReLU (tdnn_layer.py:36-39) */
+    int32_t device;        /* HIP device ordinal the handle lives on */
+} xvec_cfg;
+
+/* ---- lifetime ---------------------------------------------------------------------- */
+int xvec_create(const xvec_cfg* cfg, xvec_handle** out);
+void xvec_destroy(xvec_handle* h);
+const char* xvec_last_error(void);
+/* "gfx950 hip <build id>" */
+const char* xvec_version(void);
+
+/* ---- parameters (replaces nn.Module state: load_state_dict, main.py:213) -------------
+ * Pointers are device fp32 tensors in PyTorch layout; the library re-packs them on the
+ * device (tap-major padded weights, BatchNorm folded to scale/shift, bf16 copies).
+ *   layer 0..4: time_context_layers.{layer}.linear.{weight[out, in*|ctx|], bias[out]}
+ *               time_context_layers.{layer}.norm.{weight,bias,running_mean,running_var}[out]
+ *               (all four NULL when cfg.batch_norm == 0); eps = BatchNorm1d.eps (1e-5). */
+int xvec_load_tdnn(xvec_handle* h, int layer, const float* weight, const float* bias,
+                   const float* bn_weight, const float* bn_bias, const float* bn_mean,
+                   const float* bn_var, float eps, xvec_stream stream);
+/* which = XVEC_SEG6 / XVEC_SEG7 / XVEC_OUTPUT: {segment_layer6,segment_layer7,output}.{weight,bias} */
+int xvec_load_affine(xvec_handle* h, int which, const float* weight, const float* bias,
+                     xvec_stream stream);
+
+/* ---- whole path --------------------------------------------------------------------
+ * Bytes of scratch xvec_forward needs for B utterances totalling total_frames input
+ * frames (B*T for a fixed-length batch).  */
+size_t xvec_workspace_bytes(const xvec_handle* h, int64_t total_frames, int32_t n_utts);
+
+/* XVectorModel.forward / extract_x_vec (main.py:66-94) on x[B,T,input_size].
+ *   lengths_host: NULL (every utterance has T frames, the reference's only case) or a
+ *                 HOST array of B valid-frame counts, 15 <= lengths[i] <= T: utterance i
+ *                 is x[i, :lengths[i]] and the result equals the reference run on that
+ *                 un-padded slice alone (BASELINE config 3).
+ *   mode:         XVEC_MODE_*;  dtype: XVEC_F32 / XVEC_BF16
+ *   out:          [B, num_classes] (logits) or [B, x_vector_size]
+ * Errors: T (or a length) < 15 -> XVEC_ERR_ARG (the reference silently yields empty
+ * tensors / NaN there); weights not loaded -> XVEC_ERR_STATE. */
+int xvec_forward(xvec_handle* h, const float* x, const int32_t* lengths_host, int32_t B,
+                 int32_t T, int mode, int dtype, float* out, void* workspace,
+                 size_t workspace_bytes, xvec_stream stream);
+
+/* Same on a packed ragged batch: x_packed[offsets_host[B], input_size] holds utterance i
+ * in rows [offsets_host[i], offsets_host[i+1]). */
+int xvec_forward_packed(xvec_handle* h, const float* x_packed, const int64_t* offsets_host,
+                        int32_t B, int mode, int dtype, float* out, void* workspace,
+                        size_t workspace_bytes, xvec_stream stream);
+
+/* ---- per-stage entry points (unit tests; each mirrors one reference function) --------
+ * TdnnLayer.forward (tdnn_layer.py:26-41), eval mode, for time_context_layers.{layer}:
+ * x[B,T,in] -> y[B,T-(c[-1]-c[0]),out].  workspace >= xvec_workspace_bytes(h, B*T, B). */
+int xvec_tdnn_layer(xvec_handle* h, int layer, const float* x, int32_t B, int32_t T, int dtype,
+                    float* y, void* workspace, size_t workspace_bytes, xvec_stream stream);
+/* XVectorModel.stat_pool (main.py:59-63): x[B,T,C] -> out[B,2C] = mean ‖ unbiased std.
+ * lengths_dev: NULL or DEVICE int32[B] valid-frame counts (mask).  Stand-alone: no handle. */
+int xvec_stat_pool(const float* x, const int32_t* lengths_dev, int32_t B, int32_t T, int32_t C,
+                   float* out, xvec_stream stream);
+/* nn.Linear (+ optional F.relu) of segment_layer6 / segment_layer7 / output
+ * (main.py:72-75,87-90): x[M,in] -> y[M,out]. */
+int xvec_affine(xvec_handle* h, int which, const float* x, int32_t M, int relu, float* y,
+                xvec_stream stream);
+
+/* ---- measurement --------------------------------------------------------------------
+ * With profiling on, xvec_forward brackets every kernel with hipEvents on the caller's
+ * stream.  xvec_get_timings synchronises on the last event and returns milliseconds:
+ * ms[0..4] TDNN layers 1-5 (layer 5 includes its fused pooling epilogue), ms[5] pooling
+ * finalize / stand-alone pooling, ms[6..8] segment_layer6 / 7 / output (0 if not run),
+ * ms[9] input packing; *n = 10. */
+int xvec_set_profiling(xvec_handle* h, int on);
+int xvec_get_timings(xvec_handle* h, float* ms, int* n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XVEC_HIP_H */

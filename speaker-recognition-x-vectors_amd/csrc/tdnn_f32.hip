@@ -1,0 +1,286 @@
+// Frame-level TDNN layer for gfx950 (MI355X), exact fp32:
+//   Y[p, n] = relu( sum_{tap, c} X[p + tap*dil, c] * W[n, tap, c] + bias[n] ) * scale[n] + shift[n]
+// i.e. tdnn_layer.py:26-41 of the reference (context concat -> Linear -> ReLU -> eval
+// BatchNorm1d) as ONE implicit-GEMM kernel over the flat frame axis.  No context copy
+// (the reference's torch.cat, tdnn_layer.py:29) is ever materialised: a K-chunk that
+// belongs to tap j is staged from rows p + j*dil of the same activation buffer.
+//
+// Machine mapping (CDNA4): 256 threads = 4 wave64 in a 2x2 grid, block tile 128 frames x
+// 128 channels, each wave 64x64 as 2x2 v_mfma_f32_32x32x2_f32 tiles (64 accumulator
+// VGPRs).  K is consumed in 32-wide chunks, register-staged global -> LDS (double
+// buffered, one barrier per chunk, next chunk's global loads issued before the MFMAs of
+// the current one).  LDS rows are 128 B with a 16-B-chunk XOR swizzle so the ds_read_b128
+// fragment reads are bank-conflict free.  Each ds_read_b128 feeds four MFMAs: lane half
+// h of the wave owns k = 8q+4h..8q+4h+3 of every 8-wide k group, for A and B alike, so
+// the products pair up correctly (the k order inside a chunk is permuted, which fp32
+// addition tolerates to within rounding).
+//
+// Epilogue: bias + ReLU + folded BatchNorm in registers; optional fused statistics
+// pooling (main.py:59-63): per 64-row wave sub-tile and per utterance overlapping it, the
+// column mean and M2 (sum of squared deviations about that mean) of the valid frames are
+// written to a small partials buffer; pool_finalize merges them (Chan et al.), so the
+// [frames, 1500] activation of layer 5 never goes to HBM.
+#include "xvec_internal.h"
+
+namespace xvec {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int BM, int BN>
+struct TileCfg {
+    static constexpr int kThreads = 256;
+    static constexpr int kStageFloats = (BM + BN) * kBK;
+    static constexpr int kLdsBytes = 2 * kStageFloats * 4;
+};
+
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    // blocks b, b+8, b+16.. share an XCD (round-robin dispatch); give each XCD a
+    // contiguous run of tiles so neighbours share A rows / W columns in its L2.
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, local = bid >> 3;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + local;
+}
+
+template <int BM, int BN, bool GUARD, bool POOL, bool STORE>
+__global__ __launch_bounds__(256, 2) void tdnn_f32_kernel(const TdnnArgs a) {
+    static_assert(BM == 128 && BN == 128, "wave layout below assumes a 128x128 tile");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int kStage = TileCfg<BM, BN>::kStageFloats;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int n_tile = wg % a.n_tiles;
+    const int m_tile = wg / a.n_tiles;
+    const int64_t m0 = (int64_t)m_tile * BM;
+    const int n0 = n_tile * BN;
+
+    // ---- staging map: thread -> (row r0 + 32*j, 16-byte chunk c) of the 32-wide K chunk
+    const int c = tid & 7;
+    const int r0 = tid >> 3;
+    const int st_off = r0 * kBK + ((c ^ ((r0 >> 1) & 7)) << 2);   // + 32*j*kBK per j
+    const float* __restrict__ xrow = a.X + (m0 + r0) * (int64_t)a.ldx + c * 4;
+    const float* __restrict__ wrow = a.W + (int64_t)(n0 + r0) * a.k_pad + c * 4;
+    const int n_chunks = a.n_taps * a.cpt;
+
+    // staging registers: named scalars, not arrays (arrays indexed in unrolled loops were left
+    // in scratch by hipcc once scheduling barriers were added).
+    float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+
+#define XVEC_LOAD_A(dst_, j_)                                                                        \
+    if (GUARD) {                                                                                     \
+        const bool ok = (m0 + r0 + 32 * (j_) + row_shift < a.x_rows) && (kbase + c * 4 < a.kpt);     \
+        dst_ = ok ? *reinterpret_cast<const float4*>(xp + (int64_t)(32 * (j_)) * a.ldx)              \
+                  : make_float4(0.f, 0.f, 0.f, 0.f);                                                 \
+    } else {                                                                                         \
+        dst_ = *reinterpret_cast<const float4*>(xp + (int64_t)(32 * (j_)) * a.ldx);                  \
+    }
+    // global -> registers for K-chunk (tap, kc)
+#define XVEC_LOAD_CHUNK(tap_, kc_, it_)                                                              \
+    {                                                                                                \
+        const int64_t row_shift = (int64_t)(tap_) * a.tap_rows;                                      \
+        const int kbase = (kc_) * kBK;                                                               \
+        const float* xp = xrow + row_shift * a.ldx + kbase;                                          \
+        const float* wp = wrow + (it_) * kBK;                                                        \
+        XVEC_LOAD_A(ra0, 0) XVEC_LOAD_A(ra1, 1) XVEC_LOAD_A(ra2, 2) XVEC_LOAD_A(ra3, 3)              \
+        rb0 = *reinterpret_cast<const float4*>(wp);                                                  \
+        rb1 = *reinterpret_cast<const float4*>(wp + (int64_t)32 * a.k_pad);                          \
+        rb2 = *reinterpret_cast<const float4*>(wp + (int64_t)64 * a.k_pad);                          \
+        rb3 = *reinterpret_cast<const float4*>(wp + (int64_t)96 * a.k_pad);                          \
+    }
+#define XVEC_STORE_CHUNK(buf_)                                                                       \
+    {                                                                                                \
+        float* As_ = smem + (buf_) * kStage + st_off;                                                \
+        float* Bs_ = As_ + BM * kBK;                                                                 \
+        *reinterpret_cast<float4*>(As_) = ra0;                                                       \
+        *reinterpret_cast<float4*>(As_ + 32 * kBK) = ra1;                                            \
+        *reinterpret_cast<float4*>(As_ + 64 * kBK) = ra2;                                            \
+        *reinterpret_cast<float4*>(As_ + 96 * kBK) = ra3;                                            \
+        *reinterpret_cast<float4*>(Bs_) = rb0;                                                       \
+        *reinterpret_cast<float4*>(Bs_ + 32 * kBK) = rb1;                                            \
+        *reinterpret_cast<float4*>(Bs_ + 64 * kBK) = rb2;                                            \
+        *reinterpret_cast<float4*>(Bs_ + 96 * kBK) = rb3;                                            \
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][n][e] = 0.f;
+
+    // fragment read offsets (floats): row (base + r), logical 16-B chunk 2q+h, swizzled
+    const int sw = (r >> 1) & 7;
+    const int a_base = (wm * 64 + r) * kBK;
+    const int b_base = BM * kBK + (wn * 64 + r) * kBK;
+
+#define XVEC_LOAD_FRAGS(q_, A0, A1, B0, B1)                                                          \
+    {                                                                                                \
+        const int ko = (((2 * (q_) + h) ^ sw) << 2);                                                 \
+        A0 = *reinterpret_cast<const float4*>(S + a_base + ko);                                      \
+        A1 = *reinterpret_cast<const float4*>(S + a_base + 32 * kBK + ko);                           \
+        B0 = *reinterpret_cast<const float4*>(S + b_base + ko);                                      \
+        B1 = *reinterpret_cast<const float4*>(S + b_base + 32 * kBK + ko);                           \
+    }
+#define XVEC_MFMA16(A0, A1, B0, B1)                                                                  \
+    XVEC_MFMA4(A0.x, A1.x, B0.x, B1.x)                                                               \
+    XVEC_MFMA4(A0.y, A1.y, B0.y, B1.y)                                                               \
+    XVEC_MFMA4(A0.z, A1.z, B0.z, B1.z)                                                               \
+    XVEC_MFMA4(A0.w, A1.w, B0.w, B1.w)
+    // fragments of k-group q+1 are fetched from LDS while the 16 MFMAs of group q run
+#define XVEC_COMPUTE_CHUNK(buf_)                                                                     \
+    {                                                                                                \
+        const float* S = smem + (buf_) * kStage;                                                     \
+        float4 pa0, pa1, pb0, pb1, qa0, qa1, qb0, qb1;                                               \
+        XVEC_LOAD_FRAGS(0, pa0, pa1, pb0, pb1)                                                       \
+        XVEC_LOAD_FRAGS(1, qa0, qa1, qb0, qb1)                                                       \
+        XVEC_MFMA16(pa0, pa1, pb0, pb1)                                                              \
+        XVEC_LOAD_FRAGS(2, pa0, pa1, pb0, pb1)                                                       \
+        XVEC_MFMA16(qa0, qa1, qb0, qb1)                                                              \
+        XVEC_LOAD_FRAGS(3, qa0, qa1, qb0, qb1)                                                       \
+        XVEC_MFMA16(pa0, pa1, pb0, pb1)                                                              \
+        XVEC_MFMA16(qa0, qa1, qb0, qb1)                                                              \
+    }
+#define XVEC_MFMA4(a0_, a1_, b0_, b1_)                                                               \
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0_, b0_, acc[0][0], 0, 0, 0);                  \
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0_, b1_, acc[0][1], 0, 0, 0);                  \
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1_, b0_, acc[1][0], 0, 0, 0);                  \
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1_, b1_, acc[1][1], 0, 0, 0);
+
+    XVEC_LOAD_CHUNK(0, 0, 0)
+    XVEC_STORE_CHUNK(0)
+    __syncthreads();
+
+    // steady state: chunk `it` is in LDS buffer it&1; fetch it+1 while computing it
+    int tap = 0, kc = 0;
+    for (int it = 0; it + 1 < n_chunks; ++it) {
+        if (++kc == a.cpt) { kc = 0; ++tap; }
+        XVEC_LOAD_CHUNK(tap, kc, it + 1)
+        __builtin_amdgcn_sched_barrier(0);   // keep the global loads ahead of the MFMA block
+        XVEC_COMPUTE_CHUNK(it & 1)
+        __builtin_amdgcn_sched_barrier(0);
+        XVEC_STORE_CHUNK((it + 1) & 1)
+        __syncthreads();
+    }
+    XVEC_COMPUTE_CHUNK((n_chunks - 1) & 1)
+#undef XVEC_LOAD_CHUNK
+#undef XVEC_LOAD_A
+#undef XVEC_STORE_CHUNK
+#undef XVEC_COMPUTE_CHUNK
+#undef XVEC_MFMA4
+#undef XVEC_MFMA16
+#undef XVEC_LOAD_FRAGS
+
+    // ---- epilogue: bias + ReLU + folded BatchNorm (tdnn_layer.py:30-39) -----------------
+    // accumulator element e of lane (r, h): row = (e&3) + 8*(e>>2) + 4*h, col = r
+    const int64_t row_w = m0 + wm * 64;   // first flat row of this wave's sub-tile
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const int col = n0 + wn * 64 + n * 32 + r;
+        const float bi = a.bias[col], sc = a.scale[col], sh = a.shift[col];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float v = acc[i][n][e] + bi;
+                v = fmaxf(v, 0.f);
+                v = fmaf(v, sc, sh);
+                acc[i][n][e] = v;
+                if (STORE) {
+                    const int64_t row = row_w + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    a.Y[row * a.ldy + col] = v;
+                }
+            }
+        }
+    }
+
+    if (POOL) {
+        // ---- fused statistics pooling partials (main.py:59-63) --------------------------
+        // utterances overlapping flat rows [row_w, row_w + 64)
+        int u;
+        if (a.offsets == nullptr) {
+            u = (int)(row_w / a.fixed_T);
+        } else {
+            int lo = 0, hi = a.n_utts;              // largest u with offsets[u] <= row_w
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (a.offsets[mid] <= row_w) lo = mid; else hi = mid;
+            }
+            u = lo;
+        }
+        const int64_t sub = row_w >> 6;
+        for (; u < a.n_utts; ++u) {
+            const int64_t off = a.offsets ? a.offsets[u] : (int64_t)u * a.fixed_T;
+            if (off >= row_w + 64) break;
+            const int64_t len = a.offsets ? (a.offsets[u + 1] - off) : (int64_t)a.fixed_T;
+            const int64_t lo_r = off > row_w ? off : row_w;
+            int64_t hi_r = off + len - a.shrink;
+            if (hi_r > row_w + 64) hi_r = row_w + 64;
+            if (hi_r <= lo_r) continue;
+            const int lo_l = (int)(lo_r - row_w), hi_l = (int)(hi_r - row_w);   // local rows [lo_l, hi_l)
+            const float inv_cnt = 1.f / (float)(hi_l - lo_l);
+            float* part = a.pool_part + (sub + u) * (int64_t)(2 * a.ldy);
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                float s = 0.f;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int lr = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                        s += (lr >= lo_l && lr < hi_l) ? acc[i][n][e] : 0.f;
+                    }
+                s += __shfl_xor(s, 32);
+                const float mean = s * inv_cnt;
+                float m2 = 0.f;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int lr = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                        const float d = acc[i][n][e] - mean;
+                        m2 += (lr >= lo_l && lr < hi_l) ? d * d : 0.f;
+                    }
+                m2 += __shfl_xor(m2, 32);
+                if (h == 0) {
+                    const int col = n0 + wn * 64 + n * 32 + r;
+                    part[col] = mean;
+                    part[a.ldy + col] = m2;
+                }
+            }
+        }
+    }
+}
+
+template <bool GUARD, bool POOL, bool STORE>
+static hipError_t launch_variant(const TdnnArgs& a, hipStream_t s) {
+    constexpr int BM = 128, BN = 128;
+    auto kern = tdnn_f32_kernel<BM, BN, GUARD, POOL, STORE>;
+    static bool attr_set = false;   // per-variant; benign if raced (idempotent)
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           TileCfg<BM, BN>::kLdsBytes);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int grid = a.m_tiles * a.n_tiles;
+    constexpr int lds_bytes = TileCfg<BM, BN>::kLdsBytes;
+    kern<<<dim3(grid), dim3(256), lds_bytes, s>>>(a);
+    return hipGetLastError();
+}
+
+hipError_t launch_tdnn_f32(const TdnnArgs& a, bool guard_a, bool fuse_pool, bool store_y, hipStream_t s) {
+    if (fuse_pool) {
+        if (guard_a) return hipErrorInvalidValue;
+        return store_y ? launch_variant<false, true, true>(a, s) : launch_variant<false, true, false>(a, s);
+    }
+    return guard_a ? launch_variant<true, false, true>(a, s) : launch_variant<false, false, true>(a, s);
+}
+
+}  // namespace xvec

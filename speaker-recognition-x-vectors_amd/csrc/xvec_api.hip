@@ -1,0 +1,543 @@
+// C-ABI layer of libxvec_hip.so (see include/xvec_hip.h): handle, parameter packing,
+// workspace planning and the launch sequence of the extraction path.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "../../include/xvec_hip.h"
+#include "xvec_internal.h"
+
+using namespace xvec;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(XVEC_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),  \
+                        __FILE__, __LINE__);                                                  \
+    } while (0)
+
+// reference main.py:38-44
+const int kCtxLen[XVEC_NUM_TDNN] = {5, 3, 3, 1, 1};
+const int kCtxDil[XVEC_NUM_TDNN] = {1, 2, 3, 0, 0};
+
+enum { T_L1 = 0, T_POOL = 5, T_SEG6 = 6, T_SEG7 = 7, T_OUT = 8, T_PACK = 9, T_COUNT = 10 };
+
+}  // namespace
+
+struct xvec_handle {
+    xvec_cfg cfg;
+    int cin_pad;                       // input_size rounded up to 4 (row stride of layer-1 input)
+    TdnnGeom geo[XVEC_NUM_TDNN];
+    float* Wp[XVEC_NUM_TDNN];
+    float* vec[XVEC_NUM_TDNN];         // bias | scale | shift, n_pad each
+    bool tdnn_loaded[XVEC_NUM_TDNN];
+    float* affW[3];
+    float* affB[3];
+    int affN[3], affK[3];
+    bool aff_loaded[3];
+    // ragged batches: host offsets staged through pinned memory
+    int64_t* offs_pinned;
+    size_t offs_cap;
+    hipEvent_t offs_evt;
+    bool offs_pending;
+    // profiling
+    bool profiling;
+    hipEvent_t ev0[T_COUNT], ev1[T_COUNT];
+    bool ev_used[T_COUNT];
+};
+
+namespace {
+
+struct Plan {
+    int64_t total, m_pad, rows_alloc;
+    size_t xpad, actA, actB, act5, part, pooled, seg6, seg7, offs, bytes;
+    int64_t part_slots;
+};
+
+size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
+
+Plan make_plan(const xvec_handle* h, int64_t total, int B) {
+    Plan p;
+    p.total = total;
+    p.m_pad = round_up64(total > 0 ? total : 1, 128);
+    p.rows_alloc = p.m_pad + kRowPadTail;
+    const int nh = h->geo[0].n_pad, n5 = h->geo[4].n_pad;
+    size_t o = 0;
+    p.xpad = o;   o += align_up((size_t)p.rows_alloc * h->cin_pad * 4);
+    p.actA = o;   o += align_up((size_t)p.rows_alloc * nh * 4);
+    p.actB = o;   o += align_up((size_t)p.rows_alloc * nh * 4);
+    p.act5 = o;   o += align_up((size_t)p.rows_alloc * n5 * 4);
+    p.part_slots = p.m_pad / 64 + B + 1;
+    p.part = o;   o += align_up((size_t)p.part_slots * 2 * n5 * 4);
+    p.pooled = o; o += align_up((size_t)B * 2 * XVEC_POOL_CHANNELS * 4);
+    p.seg6 = o;   o += align_up((size_t)B * h->cfg.x_vector_size * 4);
+    p.seg7 = o;   o += align_up((size_t)B * h->cfg.x_vector_size * 4);
+    p.offs = o;   o += align_up((size_t)(B + 1) * 8);
+    p.bytes = o;
+    return p;
+}
+
+void fill_geometry(xvec_handle* h) {
+    const int hid = h->cfg.hidden_size;
+    for (int i = 0; i < XVEC_NUM_TDNN; ++i) {
+        TdnnGeom& g = h->geo[i];
+        g.src_taps = kCtxLen[i];
+        g.src_cin = (i == 0) ? h->cfg.input_size : hid;
+        g.cin = g.src_cin;
+        g.cout = (i == 4) ? XVEC_POOL_CHANNELS : hid;
+        g.n_pad = round_up(g.cout, 128);
+        g.ctx_span = (kCtxLen[i] - 1) * kCtxDil[i];
+        if (kCtxLen[i] == 1 || kCtxDil[i] == 1) {
+            // contiguous context: the taps of one output row are one contiguous run of the
+            // input buffer (row stride ldx), so they fold into a single tap of K = taps*ldx
+            const int ldx = (i == 0) ? h->cin_pad : hid;
+            g.n_taps = 1;
+            g.tap_rows = 0;
+            g.tap_stride_src = (kCtxLen[i] == 1) ? round_up(g.cin, kBK) : ldx;
+            g.kpt = (kCtxLen[i] == 1) ? g.cin : kCtxLen[i] * ldx;
+        } else {
+            g.n_taps = kCtxLen[i];
+            g.tap_rows = kCtxDil[i];
+            g.kpt = g.cin;
+            g.tap_stride_src = round_up(g.cin, kBK);
+        }
+        g.kpt_pad = round_up(g.kpt, kBK);
+        g.k_pad = g.n_taps * g.kpt_pad;
+    }
+}
+
+int aff_index(int which) { return which == XVEC_SEG6 ? 0 : which == XVEC_SEG7 ? 1 : which == XVEC_OUTPUT ? 2 : -1; }
+
+struct StageTimer {
+    xvec_handle* h;
+    int idx;
+    hipStream_t s;
+    StageTimer(xvec_handle* h_, int idx_, hipStream_t s_) : h(h_), idx(idx_), s(s_) {
+        if (h->profiling) (void)hipEventRecord(h->ev0[idx], s);
+    }
+    ~StageTimer() {
+        if (h->profiling) {
+            (void)hipEventRecord(h->ev1[idx], s);
+            h->ev_used[idx] = true;
+        }
+    }
+};
+
+// Launch one frame-level layer on flat rows.
+int run_tdnn(xvec_handle* h, int layer, const float* X, int ldx, int64_t x_rows, bool guard, float* Y,
+             const Plan& p, bool fuse_pool, bool store_y, float* part, const int64_t* offs_dev, int B,
+             int fixed_T, hipStream_t s) {
+    const TdnnGeom& g = h->geo[layer];
+    TdnnArgs a;
+    memset(&a, 0, sizeof(a));
+    a.X = X;
+    a.W = h->Wp[layer];
+    a.bias = h->vec[layer];
+    a.scale = h->vec[layer] + g.n_pad;
+    a.shift = h->vec[layer] + 2 * g.n_pad;
+    a.Y = Y;
+    a.x_rows = x_rows;
+    a.ldx = ldx;
+    a.ldy = g.n_pad;
+    a.n_taps = g.n_taps;
+    a.tap_rows = g.tap_rows;
+    a.kpt = g.kpt;
+    a.cpt = g.kpt_pad / kBK;
+    a.k_pad = g.k_pad;
+    a.m_tiles = (int)(p.m_pad / 128);
+    a.n_tiles = g.n_pad / 128;
+    a.pool_part = part;
+    a.offsets = offs_dev;
+    a.n_utts = B;
+    a.fixed_T = fixed_T;
+    a.shrink = XVEC_TOTAL_CONTEXT;
+    if ((int64_t)a.m_tiles * a.n_tiles > 0x7fffffff) return fail(XVEC_ERR_ARG, "batch too large for one launch");
+    StageTimer t(h, T_L1 + layer, s);
+    HIP_TRY(launch_tdnn_f32(a, guard, fuse_pool, store_y, s));
+    return XVEC_OK;
+}
+
+int check_loaded(const xvec_handle* h, int mode) {
+    for (int i = 0; i < XVEC_NUM_TDNN; ++i)
+        if (!h->tdnn_loaded[i]) return fail(XVEC_ERR_STATE, "time_context_layers.%d weights not loaded", i);
+    if (!h->aff_loaded[0]) return fail(XVEC_ERR_STATE, "segment_layer6 weights not loaded");
+    if ((mode == XVEC_MODE_XVEC7 || mode == XVEC_MODE_LOGITS) && !h->aff_loaded[1])
+        return fail(XVEC_ERR_STATE, "segment_layer7 weights not loaded");
+    if (mode == XVEC_MODE_LOGITS && !h->aff_loaded[2]) return fail(XVEC_ERR_STATE, "output weights not loaded");
+    return XVEC_OK;
+}
+
+// x_rows: [total, ldx] packed rows (offs_host == nullptr: B utterances of fixed_T rows each)
+int forward_rows(xvec_handle* h, const float* x_rows, int ldx, const int64_t* offs_dev, int B, int fixed_T,
+                 const Plan& p, int mode, float* out, char* ws, hipStream_t s) {
+    float* actA = reinterpret_cast<float*>(ws + p.actA);
+    float* actB = reinterpret_cast<float*>(ws + p.actB);
+    float* part = reinterpret_cast<float*>(ws + p.part);
+    float* pooled = reinterpret_cast<float*>(ws + p.pooled);
+    float* s6 = reinterpret_cast<float*>(ws + p.seg6);
+    float* s7 = reinterpret_cast<float*>(ws + p.seg7);
+    const int nh = h->geo[0].n_pad;
+    int rc;
+    // layer 1 reads the caller's rows: guarded against the end of the buffer and the K tail
+    if ((rc = run_tdnn(h, 0, x_rows, ldx, p.total, true, actA, p, false, true, nullptr, nullptr, B, fixed_T, s))) return rc;
+    if ((rc = run_tdnn(h, 1, actA, nh, 0, false, actB, p, false, true, nullptr, nullptr, B, fixed_T, s))) return rc;
+    if ((rc = run_tdnn(h, 2, actB, nh, 0, false, actA, p, false, true, nullptr, nullptr, B, fixed_T, s))) return rc;
+    if ((rc = run_tdnn(h, 3, actA, nh, 0, false, actB, p, false, true, nullptr, nullptr, B, fixed_T, s))) return rc;
+    // layer 5 with the statistics-pooling epilogue: its [frames,1500] output stays on chip
+    if ((rc = run_tdnn(h, 4, actB, nh, 0, false, nullptr, p, true, false, part, offs_dev, B, fixed_T, s))) return rc;
+    {
+        StageTimer t(h, T_POOL, s);
+        PoolFinalizeArgs f;
+        f.part = part;
+        f.out = pooled;
+        f.offsets = offs_dev;
+        f.B = B;
+        f.C = XVEC_POOL_CHANNELS;
+        f.n_pad = h->geo[4].n_pad;
+        f.fixed_T = fixed_T;
+        f.shrink = XVEC_TOTAL_CONTEXT;
+        f.sub_rows = 64;
+        HIP_TRY(launch_pool_finalize(f, s));
+    }
+    const int xv = h->cfg.x_vector_size, K6 = 2 * XVEC_POOL_CHANNELS;
+    if (mode == XVEC_MODE_XVEC6) {
+        StageTimer t(h, T_SEG6, s);
+        HIP_TRY(launch_affine_f32(pooled, h->affW[0], h->affB[0], out, B, xv, K6, 0, s));
+        return XVEC_OK;
+    }
+    {
+        StageTimer t(h, T_SEG6, s);
+        HIP_TRY(launch_affine_f32(pooled, h->affW[0], h->affB[0], s6, B, xv, K6, 1, s));
+    }
+    if (mode == XVEC_MODE_XVEC7) {
+        StageTimer t(h, T_SEG7, s);
+        HIP_TRY(launch_affine_f32(s6, h->affW[1], h->affB[1], out, B, xv, xv, 0, s));
+        return XVEC_OK;
+    }
+    {
+        StageTimer t(h, T_SEG7, s);
+        HIP_TRY(launch_affine_f32(s6, h->affW[1], h->affB[1], s7, B, xv, xv, 1, s));
+    }
+    {
+        StageTimer t(h, T_OUT, s);
+        HIP_TRY(launch_affine_f32(s7, h->affW[2], h->affB[2], out, B, h->cfg.num_classes, xv, 0, s));
+    }
+    return XVEC_OK;
+}
+
+// host offsets -> device (stream ordered, via the handle's pinned staging buffer)
+int stage_offsets(xvec_handle* h, const int64_t* offs_host, int B, int64_t* dev, hipStream_t s) {
+    const size_t n = (size_t)B + 1;
+    if (h->offs_pending) {               // previous batch's copy must have left the pinned buffer
+        HIP_TRY(hipEventSynchronize(h->offs_evt));
+        h->offs_pending = false;
+    }
+    if (n > h->offs_cap) {
+        if (h->offs_pinned) HIP_TRY(hipHostFree(h->offs_pinned));
+        h->offs_pinned = nullptr;
+        h->offs_cap = 0;
+        size_t cap = n < 4096 ? 4096 : n * 2;
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->offs_pinned), cap * 8, hipHostMallocDefault));
+        h->offs_cap = cap;
+    }
+    memcpy(h->offs_pinned, offs_host, n * 8);
+    HIP_TRY(hipMemcpyAsync(dev, h->offs_pinned, n * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipEventRecord(h->offs_evt, s));
+    h->offs_pending = true;
+    return XVEC_OK;
+}
+
+int common_checks(xvec_handle* h, const void* x, int B, int mode, int dtype, const void* out, const void* ws) {
+    if (!h) return fail(XVEC_ERR_ARG, "null handle");
+    if (!x || !out || !ws) return fail(XVEC_ERR_ARG, "null tensor pointer");
+    if (B < 1) return fail(XVEC_ERR_ARG, "B must be >= 1 (got %d)", B);
+    if (mode != XVEC_MODE_LOGITS && mode != XVEC_MODE_XVEC6 && mode != XVEC_MODE_XVEC7)
+        return fail(XVEC_ERR_ARG, "unknown mode %d", mode);
+    if (dtype != XVEC_F32) return fail(XVEC_ERR_ARG, "dtype %d not supported by this build (fp32 only)", dtype);
+    if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(ws) & 255))
+        return fail(XVEC_ERR_ARG, "x must be 16-byte and workspace 256-byte aligned");
+    return check_loaded(h, mode);
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* xvec_last_error(void) { return g_err; }
+const char* xvec_version(void) { return "xvec_hip gfx950 0.1 (" __DATE__ ")"; }
+
+int xvec_create(const xvec_cfg* cfg, xvec_handle** out) {
+    if (!cfg || !out) return fail(XVEC_ERR_ARG, "null argument");
+    if (cfg->input_size < 1 || cfg->hidden_size < 1 || cfg->num_classes < 1 || cfg->x_vector_size < 1)
+        return fail(XVEC_ERR_ARG, "sizes must be positive");
+    HIP_TRY(hipSetDevice(cfg->device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, cfg->device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(XVEC_ERR_STATE, "device %d is %s; this library is built for gfx950 only", cfg->device,
+                    prop.gcnArchName);
+    xvec_handle* h = new (std::nothrow) xvec_handle();
+    if (!h) return fail(XVEC_ERR_STATE, "out of host memory");
+    memset(h, 0, sizeof(*h));
+    h->cfg = *cfg;
+    h->cin_pad = round_up(cfg->input_size, 4);
+    fill_geometry(h);
+    for (int i = 0; i < XVEC_NUM_TDNN; ++i) {
+        const TdnnGeom& g = h->geo[i];
+        if (hipMalloc(reinterpret_cast<void**>(&h->Wp[i]), (size_t)g.n_pad * g.k_pad * 4) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void**>(&h->vec[i]), (size_t)3 * g.n_pad * 4) != hipSuccess) {
+            xvec_destroy(h);
+            return fail(XVEC_ERR_HIP, "hipMalloc of packed weights failed");
+        }
+    }
+    const int N[3] = {cfg->x_vector_size, cfg->x_vector_size, cfg->num_classes};
+    const int K[3] = {2 * XVEC_POOL_CHANNELS, cfg->x_vector_size, cfg->x_vector_size};
+    for (int i = 0; i < 3; ++i) {
+        h->affN[i] = N[i];
+        h->affK[i] = K[i];
+        if (hipMalloc(reinterpret_cast<void**>(&h->affW[i]), (size_t)N[i] * K[i] * 4) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void**>(&h->affB[i]), (size_t)N[i] * 4) != hipSuccess) {
+            xvec_destroy(h);
+            return fail(XVEC_ERR_HIP, "hipMalloc of affine weights failed");
+        }
+    }
+    bool ok = hipEventCreateWithFlags(&h->offs_evt, hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; i < T_COUNT && ok; ++i)
+        ok = hipEventCreate(&h->ev0[i]) == hipSuccess && hipEventCreate(&h->ev1[i]) == hipSuccess;
+    if (!ok) {
+        xvec_destroy(h);
+        return fail(XVEC_ERR_HIP, "hipEventCreate failed");
+    }
+    *out = h;
+    return XVEC_OK;
+}
+
+void xvec_destroy(xvec_handle* h) {
+    if (!h) return;
+    for (int i = 0; i < XVEC_NUM_TDNN; ++i) {
+        if (h->Wp[i]) (void)hipFree(h->Wp[i]);
+        if (h->vec[i]) (void)hipFree(h->vec[i]);
+    }
+    for (int i = 0; i < 3; ++i) {
+        if (h->affW[i]) (void)hipFree(h->affW[i]);
+        if (h->affB[i]) (void)hipFree(h->affB[i]);
+    }
+    if (h->offs_pinned) (void)hipHostFree(h->offs_pinned);
+    if (h->offs_evt) (void)hipEventDestroy(h->offs_evt);
+    for (int i = 0; i < T_COUNT; ++i) {
+        if (h->ev0[i]) (void)hipEventDestroy(h->ev0[i]);
+        if (h->ev1[i]) (void)hipEventDestroy(h->ev1[i]);
+    }
+    delete h;
+}
+
+int xvec_load_tdnn(xvec_handle* h, int layer, const float* weight, const float* bias, const float* bn_weight,
+                   const float* bn_bias, const float* bn_mean, const float* bn_var, float eps, xvec_stream stream) {
+    if (!h || layer < 0 || layer >= XVEC_NUM_TDNN) return fail(XVEC_ERR_ARG, "bad handle or layer %d", layer);
+    if (!weight || !bias) return fail(XVEC_ERR_ARG, "null weight/bias");
+    const bool has_bn = bn_weight && bn_bias && bn_mean && bn_var;
+    const bool none_bn = !bn_weight && !bn_bias && !bn_mean && !bn_var;
+    if (h->cfg.batch_norm ? !has_bn : !none_bn)
+        return fail(XVEC_ERR_ARG, "BatchNorm tensors must be %s for batch_norm=%d",
+                    h->cfg.batch_norm ? "all given" : "all NULL", h->cfg.batch_norm);
+    const TdnnGeom& g = h->geo[layer];
+    HIP_TRY(launch_pack_tdnn(weight, bias, bn_weight, bn_bias, bn_mean, bn_var, eps, g, h->Wp[layer],
+                             h->vec[layer], h->vec[layer] + g.n_pad, h->vec[layer] + 2 * g.n_pad,
+                             static_cast<hipStream_t>(stream)));
+    h->tdnn_loaded[layer] = true;
+    return XVEC_OK;
+}
+
+int xvec_load_affine(xvec_handle* h, int which, const float* weight, const float* bias, xvec_stream stream) {
+    const int i = aff_index(which);
+    if (!h || i < 0) return fail(XVEC_ERR_ARG, "bad handle or affine id %d", which);
+    if (!weight || !bias) return fail(XVEC_ERR_ARG, "null weight/bias");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    HIP_TRY(hipMemcpyAsync(h->affW[i], weight, (size_t)h->affN[i] * h->affK[i] * 4, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemcpyAsync(h->affB[i], bias, (size_t)h->affN[i] * 4, hipMemcpyDeviceToDevice, s));
+    h->aff_loaded[i] = true;
+    return XVEC_OK;
+}
+
+size_t xvec_workspace_bytes(const xvec_handle* h, int64_t total_frames, int32_t n_utts) {
+    if (!h || total_frames < 1 || n_utts < 1) return 0;
+    return make_plan(h, total_frames, n_utts).bytes;
+}
+
+int xvec_forward(xvec_handle* h, const float* x, const int32_t* lengths_host, int32_t B, int32_t T, int mode,
+                 int dtype, float* out, void* workspace, size_t workspace_bytes, xvec_stream stream) {
+    int rc = common_checks(h, x, B, mode, dtype, out, workspace);
+    if (rc) return rc;
+    if (T <= XVEC_TOTAL_CONTEXT)
+        return fail(XVEC_ERR_ARG, "T=%d: need at least %d frames (receptive field of the TDNN stack)", T,
+                    XVEC_TOTAL_CONTEXT + 1);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    char* ws = static_cast<char*>(workspace);
+    const int C = h->cfg.input_size;
+
+    if (!lengths_host) {
+        const Plan p = make_plan(h, (int64_t)B * T, B);
+        if (workspace_bytes < p.bytes)
+            return fail(XVEC_ERR_WORKSPACE, "workspace too small: %zu < %zu", workspace_bytes, p.bytes);
+        const float* rows = x;
+        if (h->cin_pad != C) {   // channel count not a multiple of 4: pad rows once
+            StageTimer t(h, T_PACK, s);
+            float* xp = reinterpret_cast<float*>(ws + p.xpad);
+            HIP_TRY(launch_pack_rows(x, nullptr, B, T, C, h->cin_pad, xp, s));
+            rows = xp;
+        }
+        return forward_rows(h, rows, h->cin_pad, nullptr, B, T, p, mode, out, ws, s);
+    }
+
+    // ragged: pack the valid frames, run the stack on sum(lengths) rows only
+    int64_t total = 0;
+    for (int i = 0; i < B; ++i) {
+        const int n = lengths_host[i];
+        if (n <= XVEC_TOTAL_CONTEXT || n > T)
+            return fail(XVEC_ERR_ARG, "lengths[%d]=%d outside [%d, T=%d]", i, n, XVEC_TOTAL_CONTEXT + 1, T);
+        total += n;
+    }
+    const Plan p = make_plan(h, total, B);
+    if (workspace_bytes < p.bytes)
+        return fail(XVEC_ERR_WORKSPACE, "workspace too small: %zu < %zu", workspace_bytes, p.bytes);
+    {
+        // offsets built directly in the pinned buffer would race with a pending copy: build on stack/heap
+        int64_t* tmp = new (std::nothrow) int64_t[(size_t)B + 1];
+        if (!tmp) return fail(XVEC_ERR_STATE, "out of host memory");
+        tmp[0] = 0;
+        for (int i = 0; i < B; ++i) tmp[i + 1] = tmp[i] + lengths_host[i];
+        rc = stage_offsets(h, tmp, B, reinterpret_cast<int64_t*>(ws + p.offs), s);
+        delete[] tmp;
+        if (rc) return rc;
+    }
+    const int64_t* offs_dev = reinterpret_cast<const int64_t*>(ws + p.offs);
+    float* xp = reinterpret_cast<float*>(ws + p.xpad);
+    {
+        StageTimer t(h, T_PACK, s);
+        HIP_TRY(launch_pack_rows(x, offs_dev, B, T, C, h->cin_pad, xp, s));
+    }
+    return forward_rows(h, xp, h->cin_pad, offs_dev, B, 0, p, mode, out, ws, s);
+}
+
+int xvec_forward_packed(xvec_handle* h, const float* x_packed, const int64_t* offsets_host, int32_t B, int mode,
+                        int dtype, float* out, void* workspace, size_t workspace_bytes, xvec_stream stream) {
+    int rc = common_checks(h, x_packed, B, mode, dtype, out, workspace);
+    if (rc) return rc;
+    if (!offsets_host) return fail(XVEC_ERR_ARG, "null offsets");
+    if (offsets_host[0] != 0) return fail(XVEC_ERR_ARG, "offsets[0] must be 0");
+    for (int i = 0; i < B; ++i) {
+        const int64_t n = offsets_host[i + 1] - offsets_host[i];
+        if (n <= XVEC_TOTAL_CONTEXT)
+            return fail(XVEC_ERR_ARG, "utterance %d has %lld frames; need at least %d", i, (long long)n,
+                        XVEC_TOTAL_CONTEXT + 1);
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    char* ws = static_cast<char*>(workspace);
+    const int64_t total = offsets_host[B];
+    const Plan p = make_plan(h, total, B);
+    if (workspace_bytes < p.bytes)
+        return fail(XVEC_ERR_WORKSPACE, "workspace too small: %zu < %zu", workspace_bytes, p.bytes);
+    if ((rc = stage_offsets(h, offsets_host, B, reinterpret_cast<int64_t*>(ws + p.offs), s))) return rc;
+    const int64_t* offs_dev = reinterpret_cast<const int64_t*>(ws + p.offs);
+    const float* rows = x_packed;
+    const int C = h->cfg.input_size;
+    if (h->cin_pad != C) {
+        if (total > 0x7fffffff) return fail(XVEC_ERR_ARG, "too many frames");
+        StageTimer t(h, T_PACK, s);
+        float* xp = reinterpret_cast<float*>(ws + p.xpad);
+        HIP_TRY(launch_pack_rows(x_packed, nullptr, 1, (int)total, C, h->cin_pad, xp, s));
+        rows = xp;
+    }
+    return forward_rows(h, rows, h->cin_pad, offs_dev, B, 0, p, mode, out, ws, s);
+}
+
+int xvec_tdnn_layer(xvec_handle* h, int layer, const float* x, int32_t B, int32_t T, int dtype, float* y,
+                    void* workspace, size_t workspace_bytes, xvec_stream stream) {
+    if (!h || layer < 0 || layer >= XVEC_NUM_TDNN) return fail(XVEC_ERR_ARG, "bad handle or layer %d", layer);
+    if (!x || !y || !workspace) return fail(XVEC_ERR_ARG, "null tensor pointer");
+    if (dtype != XVEC_F32) return fail(XVEC_ERR_ARG, "dtype %d not supported by this build (fp32 only)", dtype);
+    if (!h->tdnn_loaded[layer]) return fail(XVEC_ERR_STATE, "time_context_layers.%d weights not loaded", layer);
+    const TdnnGeom& g = h->geo[layer];
+    if (B < 1 || T <= g.ctx_span) return fail(XVEC_ERR_ARG, "need B>=1 and T>%d (got B=%d T=%d)", g.ctx_span, B, T);
+    const Plan p = make_plan(h, (int64_t)B * T, B);
+    if (workspace_bytes < p.bytes)
+        return fail(XVEC_ERR_WORKSPACE, "workspace too small: %zu < %zu", workspace_bytes, p.bytes);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    char* ws = static_cast<char*>(workspace);
+    // stage the compact input into the layer's native row layout (stride = producer's n_pad)
+    const int ldx = (layer == 0) ? h->cin_pad : h->geo[layer - 1].n_pad;
+    float* xin = reinterpret_cast<float*>(ws + (layer == 0 ? p.xpad : p.actA));
+    HIP_TRY(launch_pack_rows(x, nullptr, B, T, g.src_cin, ldx, xin, s));
+    float* yflat = reinterpret_cast<float*>(ws + (layer == 4 ? p.act5 : p.actB));
+    int rc = run_tdnn(h, layer, xin, ldx, p.total, layer == 0, yflat, p, false, true, nullptr, nullptr, B, T, s);
+    if (rc) return rc;
+    HIP_TRY(launch_unpack_rows(yflat, g.n_pad, B, T, T - g.ctx_span, g.cout, y, s));
+    return XVEC_OK;
+}
+
+int xvec_stat_pool(const float* x, const int32_t* lengths_dev, int32_t B, int32_t T, int32_t C, float* out,
+                   xvec_stream stream) {
+    if (!x || !out) return fail(XVEC_ERR_ARG, "null tensor pointer");
+    if (B < 1 || T < 1 || C < 1) return fail(XVEC_ERR_ARG, "B, T, C must be positive");
+    if (B > 65535) return fail(XVEC_ERR_ARG, "B > 65535 not supported by the stand-alone pooling kernel");
+    PoolArgs a;
+    memset(&a, 0, sizeof(a));
+    a.X = x;
+    a.out = out;
+    a.lengths = lengths_dev;
+    a.B = B;
+    a.C = C;
+    a.ld = C;
+    a.fixed_T = T;
+    a.fixed_n = T;
+    HIP_TRY(launch_stat_pool(a, static_cast<hipStream_t>(stream)));
+    return XVEC_OK;
+}
+
+int xvec_affine(xvec_handle* h, int which, const float* x, int32_t M, int relu, float* y, xvec_stream stream) {
+    const int i = aff_index(which);
+    if (!h || i < 0) return fail(XVEC_ERR_ARG, "bad handle or affine id %d", which);
+    if (!x || !y || M < 1) return fail(XVEC_ERR_ARG, "bad x/y/M");
+    if (!h->aff_loaded[i]) return fail(XVEC_ERR_STATE, "affine %d weights not loaded", which);
+    HIP_TRY(launch_affine_f32(x, h->affW[i], h->affB[i], y, M, h->affN[i], h->affK[i], relu,
+                              static_cast<hipStream_t>(stream)));
+    return XVEC_OK;
+}
+
+int xvec_set_profiling(xvec_handle* h, int on) {
+    if (!h) return fail(XVEC_ERR_ARG, "null handle");
+    h->profiling = on != 0;
+    for (int i = 0; i < T_COUNT; ++i) h->ev_used[i] = false;
+    return XVEC_OK;
+}
+
+int xvec_get_timings(xvec_handle* h, float* ms, int* n) {
+    if (!h || !ms || !n) return fail(XVEC_ERR_ARG, "null argument");
+    for (int i = 0; i < T_COUNT; ++i) {
+        ms[i] = 0.f;
+        if (h->ev_used[i]) {
+            HIP_TRY(hipEventSynchronize(h->ev1[i]));
+            HIP_TRY(hipEventElapsedTime(&ms[i], h->ev0[i], h->ev1[i]));
+        }
+    }
+    *n = T_COUNT;
+    return XVEC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,142 @@
+"""Callers on either side of the hot path: utterance-sharded extraction over the GPUs of one
+node, and the reference's x-vector record / CSV format.
+
+Reference behaviour mirrored here (not its code):
+  * main.py:135-146  test_step/test_epoch_end: each row of the [B,512] fp32 result becomes
+    (id: str, label: int, vec: float64[512]) appended in input order;
+  * main.py:246-247  pd.DataFrame(x_vector).to_csv(path)  -> columns ",0,1,2";
+  * main.py:276-279  reader: np.array(s[1:-1].split(), dtype=float64) on column 3.
+
+Multi-GPU: the path shards by utterance with no cross-GPU dependency, so
+rank r of W takes the contiguous block [r*ceil(N/W), ...) and the only collective is one
+all-gather of the [N/W, 512] fp32 embeddings (RCCL over xGMI when the backend is "nccl").
+"""
+from __future__ import annotations
+
+from typing import Callable, Iterable, List, Sequence, Tuple
+
+import numpy as np
+import torch
+
+
+# --------------------------------------------------------------------------- sharding
+def shard_bounds(n_total: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous utterance block of `rank`: ceil(n/world) utterances each, the tail ranks
+    get the remainder (possibly none)."""
+    per = -(-n_total // world)
+    lo = min(rank * per, n_total)
+    return lo, min(lo + per, n_total)
+
+
+def balanced_order(lengths: Sequence[int], world: int) -> List[List[int]]:
+    """Variable-length batches: assign utterances to ranks greedily by total frames
+    (longest first), so every GPU gets about the same number of frames.  Returns the
+    utterance indices per rank; gather_embeddings(order=...) undoes the permutation."""
+    loads = [0] * world
+    buckets: List[List[int]] = [[] for _ in range(world)]
+    for i in sorted(range(len(lengths)), key=lambda j: -int(lengths[j])):
+        r = loads.index(min(loads))
+        buckets[r].append(i)
+        loads[r] += int(lengths[i])
+    return [sorted(b) for b in buckets]
+
+
+def gather_embeddings(local: torch.Tensor, n_total: int, group=None,
+                      order: Sequence[Sequence[int]] = None) -> torch.Tensor:
+    """All-gather the per-rank [n_local, D] embeddings into [n_total, D] on every rank.
+
+    One all_gather_into_tensor of equal-size (padded) shards; rows are then trimmed back
+    (contiguous-block sharding) or scattered to their original positions (`order`)."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return local
+    D = local.shape[1]
+    if order is None:
+        counts = [shard_bounds(n_total, r, world)[1] - shard_bounds(n_total, r, world)[0] for r in range(world)]
+    else:
+        counts = [len(o) for o in order]
+    per = max(counts)
+    send = local
+    if local.shape[0] != per:
+        send = torch.zeros((per, D), dtype=local.dtype, device=local.device)
+        send[: local.shape[0]] = local
+    recv = torch.empty((world * per, D), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(recv, send.contiguous(), group=group)
+    if order is None:
+        if all(c == per for c in counts):
+            return recv
+        return torch.cat([recv[r * per: r * per + counts[r]] for r in range(world)], 0)
+    out = torch.empty((n_total, D), dtype=local.dtype, device=local.device)
+    for r in range(world):
+        if counts[r]:
+            idx = torch.as_tensor(list(order[r]), dtype=torch.long, device=local.device)
+            out[idx] = recv[r * per: r * per + counts[r]]
+    return out
+
+
+def extract_sharded(extract_fn: Callable[[torch.Tensor], torch.Tensor], make_batch: Callable[[int, int], torch.Tensor],
+                    n_total: int, batch_size: int = 256, group=None) -> torch.Tensor:
+    """Utterance-sharded extraction job (BASELINE config 4).
+
+    make_batch(lo, hi) returns the device tensor [hi-lo, T, C] for global utterances
+    lo..hi-1 (a loader, or an on-device generator in the benchmark); extract_fn is
+    model.extract_x_vec.  Every rank returns the full [n_total, D] matrix."""
+    import torch.distributed as dist
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    lo, hi = shard_bounds(n_total, rank, world)
+    parts = []
+    for b0 in range(lo, hi, batch_size):
+        b1 = min(b0 + batch_size, hi)
+        parts.append(extract_fn(make_batch(b0, b1)))
+    if parts:
+        local = torch.cat(parts, 0)
+    else:   # rank without work still has to join the collective: learn D from a peer-sized dummy
+        probe = extract_fn(make_batch(0, 1))
+        local = probe[:0]
+    return gather_embeddings(local, n_total, group)
+
+
+# --------------------------------------------------------------------------- records / CSV
+def to_records(x_vecs: torch.Tensor, labels, ids) -> List[tuple]:
+    """[B,D] fp32 device tensor -> [(id, int(label), float64[D])] in input order with ONE
+    device-to-host copy (the reference does B of them, main.py:144-145).  The fp32->float64
+    widening is exact, so records equal the reference's bit for bit given equal x_vecs."""
+    host = x_vecs.detach().to("cpu", torch.float32).numpy()
+    if torch.is_tensor(labels):
+        labels = labels.detach().cpu().numpy()
+    return [(i, int(l), np.array(v, dtype=np.float64)) for v, l, i in zip(host, labels, ids)]
+
+
+def extract_x_vectors(model, loader: Iterable) -> List[tuple]:
+    """Lightning-free stand-in for `trainer.test(model)` in extraction mode
+    (main.py:237-267): runs model.test_step on every batch and collects the records the
+    reference accumulates in its module-global `x_vector` list."""
+    records: List[tuple] = []
+    dev = next(model.parameters()).device
+    for bi, (samples, labels, ids) in enumerate(loader):
+        for x_vec, lab, idd in model.test_step((samples.to(dev), labels, ids), bi):
+            records.extend(to_records(x_vec, lab, idd))
+    return records
+
+
+def write_x_vector_csv(records: List[tuple], path: str, npy_sidecar: bool = True):
+    """Same file the reference writes (pd.DataFrame(x_vector).to_csv): header ',0,1,2',
+    vector column = numpy's str() of the float64 array (8 significant digits -- lossy, kept
+    for drop-in compatibility); the exact vectors go to `<path>.npy` as a side-car."""
+    import pandas as pd
+    pd.DataFrame(records).to_csv(path)
+    if npy_sidecar and records:
+        np.save(path + ".npy", np.stack([r[2] for r in records]))
+
+
+def read_x_vector_csv(path: str):
+    """The reference's reader (main.py:276-279, plda_score_stat.py:16-17): returns
+    (ids, labels, vectors[float64])."""
+    import pandas as pd
+    df = pd.read_csv(path)
+    ids = np.array(df.iloc[:, 1])
+    labels = np.array(df.iloc[:, 2], dtype=int)
+    vecs = np.array([np.array(s[1:-1].split(), dtype=np.float64) for s in df.iloc[:, 3]])
+    return ids, labels, vecs

@@ -1,0 +1,78 @@
+"""ctypes binding of libxvec_hip.so (C ABI: include/xvec_hip.h).
+
+The library is the product; there is no CPU or eager-PyTorch fallback.  If the shared
+object has not been built (python -c "import __graft_entry__ as g; g.build()") or cannot
+be loaded, importing this module raises immediately.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libxvec_hip.so")
+
+OK, ERR_ARG, ERR_HIP, ERR_STATE, ERR_WORKSPACE = 0, 1, 2, 3, 4
+F32, BF16 = 0, 1
+MODE_LOGITS, MODE_XVEC6, MODE_XVEC7 = 0, 6, 7
+SEG6, SEG7, OUTPUT = 6, 7, 8
+TIMING_NAMES = ("tdnn1", "tdnn2", "tdnn3", "tdnn4", "tdnn5_pool", "pool_finalize",
+                "segment6", "segment7", "output", "pack")
+
+
+class XvecError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"xvec_hip error {code}: {msg}")
+        self.code = code
+
+
+class Cfg(C.Structure):
+    _fields_ = [("input_size", C.c_int32), ("hidden_size", C.c_int32), ("num_classes", C.c_int32),
+                ("x_vector_size", C.c_int32), ("batch_norm", C.c_int32), ("device", C.c_int32)]
+
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: build the HIP library first "
+        "(python -c 'import __graft_entry__ as g; g.build()' or make -C "
+        f"{os.path.join(_HERE, 'csrc')}). There is no CPU fallback.")
+
+lib = C.CDLL(LIB_PATH)
+
+_vp, _i32, _i64, _f32p = C.c_void_p, C.c_int32, C.c_int64, C.c_void_p
+_SIGS = {
+    "xvec_create": (C.c_int, [C.POINTER(Cfg), C.POINTER(_vp)]),
+    "xvec_destroy": (None, [_vp]),
+    "xvec_last_error": (C.c_char_p, []),
+    "xvec_version": (C.c_char_p, []),
+    "xvec_load_tdnn": (C.c_int, [_vp, C.c_int, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_float, _vp]),
+    "xvec_load_affine": (C.c_int, [_vp, C.c_int, _f32p, _f32p, _vp]),
+    "xvec_workspace_bytes": (C.c_size_t, [_vp, _i64, _i32]),
+    "xvec_forward": (C.c_int, [_vp, _f32p, C.POINTER(_i32), _i32, _i32, C.c_int, C.c_int, _f32p, _vp,
+                               C.c_size_t, _vp]),
+    "xvec_forward_packed": (C.c_int, [_vp, _f32p, C.POINTER(_i64), _i32, C.c_int, C.c_int, _f32p, _vp,
+                                      C.c_size_t, _vp]),
+    "xvec_tdnn_layer": (C.c_int, [_vp, C.c_int, _f32p, _i32, _i32, C.c_int, _f32p, _vp, C.c_size_t, _vp]),
+    "xvec_stat_pool": (C.c_int, [_f32p, _vp, _i32, _i32, _i32, _f32p, _vp]),
+    "xvec_affine": (C.c_int, [_vp, C.c_int, _f32p, _i32, C.c_int, _f32p, _vp]),
+    "xvec_set_profiling": (C.c_int, [_vp, C.c_int]),
+    "xvec_get_timings": (C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
+}
+EXPORTS = tuple(_SIGS)
+for _name, (_res, _args) in _SIGS.items():
+    _fn = getattr(lib, _name)      # AttributeError here = header/library mismatch
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+
+def last_error() -> str:
+    return lib.xvec_last_error().decode()
+
+
+def check(rc: int):
+    if rc != OK:
+        raise XvecError(rc, last_error())
+
+
+def version() -> str:
+    return lib.xvec_version().decode()

@@ -1,0 +1,360 @@
+"""Host-side mirror of the reference's model surface for the extraction path.
+
+Same names, constructor arguments, state_dict keys and call signatures as
+`tdnn_layer.TdnnLayer` / `get_time_context` (reference tdnn_layer.py:5-60) and
+`main.XVectorModel` (reference main.py:23-94), so `extract_x_vectors` in the reference's
+driver is a drop-in: `test_step` calls `self.extract_x_vec(samples.float())`
+(main.py:137) and gets the same [B, x_vector_size] fp32 tensor back.
+
+Every forward here runs on the MI355X through libxvec_hip.so (ctypes, raw device
+pointers, torch's current HIP stream).  PyTorch is plumbing only: device memory,
+streams, parameter containers.  There is NO eager / CPU fallback: a CPU tensor, a
+missing library or training mode raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence
+
+import torch
+import torch.nn as nn
+
+from . import hip as _hip
+
+TOTAL_CONTEXT = 14
+POOL_CHANNELS = 1500
+_CONTEXTS = [[-2, -1, 0, 1, 2], [-2, 0, 2], [-3, 0, 3], [0], [0]]
+_DTYPES = {"fp32": _hip.F32, "f32": _hip.F32, "bf16": _hip.BF16}
+
+
+def get_time_context(x: torch.Tensor, c: Sequence[int] = (0,)) -> List[torch.Tensor]:
+    """Time-shifted views of x[B,T,C], one per context offset (reference
+    tdnn_layer.py:43-60).  Pure view arithmetic -- kept for API compatibility; the HIP
+    kernels never materialise the concatenation, they index rows p + offset directly."""
+    last = len(c) - 1
+    lo, hi = c[0], c[last]
+    return [x[:, hi + cc: (lo + cc if cc != hi else None), :] for cc in c]
+
+
+def _stream_ptr(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _require_gpu(x: torch.Tensor, what: str):
+    if not x.is_cuda:
+        raise RuntimeError(f"{what}: expected a tensor on a HIP device, got {x.device}; "
+                           "this package has no CPU path (the CPU oracle lives in oracle/ for tests only)")
+
+
+class _Engine:
+    """One libxvec_hip handle per (model, device) plus its cached workspace."""
+
+    def __init__(self, cfg: dict, device: torch.device):
+        self.device = device
+        self.cfg = _hip.Cfg(cfg["input_size"], cfg["hidden_size"], cfg["num_classes"], cfg["x_vector_size"],
+                            int(cfg["batch_norm"]), device.index if device.index is not None else
+                            torch.cuda.current_device())
+        h = C.c_void_p()
+        _hip.check(_hip.lib.xvec_create(C.byref(self.cfg), C.byref(h)))
+        self.h = h
+        self.workspace: Optional[torch.Tensor] = None
+        self.signature = None
+
+    def __del__(self):
+        h, self.h = getattr(self, "h", None), None
+        if h:
+            try:
+                _hip.lib.xvec_destroy(h)
+            except Exception:
+                pass
+
+    def ensure_workspace(self, total_frames: int, n_utts: int):
+        need = _hip.lib.xvec_workspace_bytes(self.h, total_frames, n_utts)
+        if need == 0:
+            raise _hip.XvecError(_hip.ERR_ARG, "xvec_workspace_bytes returned 0")
+        if self.workspace is None or self.workspace.numel() < need:
+            self.workspace = None          # release before growing
+            self.workspace = torch.empty(int(need * 1.25) if total_frames > 4096 else need, dtype=torch.uint8,
+                                         device=self.device)
+        return self.workspace.data_ptr(), self.workspace.numel()
+
+
+class TdnnLayer(nn.Module):
+    """Parameter container + single-layer entry point with the reference's constructor
+    (tdnn_layer.py:6-24).  forward(x[B,T,in]) -> [B, T-(c[-1]-c[0]), out] runs the fused
+    HIP layer (context gather + Linear + ReLU + eval BatchNorm in one kernel)."""
+
+    def __init__(self, input_size=24, output_size=512, context=[0], batch_norm=True, dropout_p=0.0):
+        super().__init__()
+        self.input_size = input_size
+        self.output_size = output_size
+        self.context = context
+        self.batch_norm = batch_norm
+        self.dropout_p = dropout_p
+        self.linear = nn.Linear(input_size * len(context), output_size)
+        self.relu = nn.ReLU()
+        if self.batch_norm:
+            self.norm = nn.BatchNorm1d(output_size)
+        if self.dropout_p:
+            self.drop = nn.Dropout(p=self.dropout_p)
+        self._owner = None      # (weakref to XVectorModel, layer index), set by the parent
+        self._index = None
+
+    def forward(self, x):
+        owner = self._owner() if self._owner is not None else None
+        if owner is None:
+            raise RuntimeError("TdnnLayer must belong to an XVectorModel (its HIP engine owns the packed weights)")
+        return owner._tdnn_layer(self._index, x)
+
+
+class XVectorModel(nn.Module):
+    """reference main.XVectorModel (main.py:23-94) on MI355X.
+
+    Constructor arguments are the reference's; `batch_size`, `learning_rate`,
+    `augmentations_per_sample` and `data_folder_path` belong to its training harness and
+    are accepted and stored only.  Extensions: every entry point takes an optional
+    `lengths` (valid frames per utterance of a zero-padded batch, BASELINE config 3) and
+    `precision` selects the frame-level arithmetic ("fp32" default)."""
+
+    def __init__(self, input_size=24, hidden_size=512, num_classes=1211, x_vector_size=512,
+                 x_vec_extract_layer=6, batch_size=512, learning_rate=0.001, batch_norm=True,
+                 dropout_p=0.0, augmentations_per_sample=2, data_folder_path='data', precision="fp32"):
+        super().__init__()
+        kw = dict(batch_norm=batch_norm, dropout_p=dropout_p)
+        self.time_context_layers = nn.Sequential(
+            TdnnLayer(input_size=input_size, output_size=hidden_size, context=_CONTEXTS[0], **kw),
+            TdnnLayer(input_size=hidden_size, output_size=hidden_size, context=_CONTEXTS[1], **kw),
+            TdnnLayer(input_size=hidden_size, output_size=hidden_size, context=_CONTEXTS[2], **kw),
+            TdnnLayer(input_size=hidden_size, output_size=hidden_size, **kw),
+            TdnnLayer(input_size=hidden_size, output_size=POOL_CHANNELS, **kw),
+        )
+        self.segment_layer6 = nn.Linear(2 * POOL_CHANNELS, x_vector_size)
+        self.segment_layer7 = nn.Linear(x_vector_size, x_vector_size)
+        self.output = nn.Linear(x_vector_size, num_classes)
+
+        self.x_vec_extract_layer = x_vec_extract_layer
+        self.batch_size = batch_size
+        self.learning_rate = learning_rate
+        self.augmentations_per_sample = augmentations_per_sample
+        self.data_folder_path = data_folder_path
+        self.precision = precision
+        self.hparams = dict(input_size=input_size, hidden_size=hidden_size, num_classes=num_classes,
+                            x_vector_size=x_vector_size, batch_norm=bool(batch_norm), dropout_p=dropout_p)
+        import weakref
+        ref = weakref.ref(self)
+        for i, layer in enumerate(self.time_context_layers):
+            layer._owner, layer._index = ref, i
+        self._engines = {}
+        self.eval()   # extraction-only build: BatchNorm always uses running statistics
+
+    # ------------------------------------------------------------------ engine plumbing
+    def _check_mode(self):
+        if self.training:
+            raise RuntimeError(
+                "XVectorModel is in training mode: batch-statistics BatchNorm and autograd are outside this "
+                "build's scope (extraction path only). Call model.eval(); train with the reference and load "
+                "its checkpoint here.")
+
+    def _engine(self, device: torch.device) -> _Engine:
+        key = (device.type, device.index)
+        eng = self._engines.get(key)
+        if eng is None:
+            eng = self._engines[key] = _Engine(self.hparams, device)
+        self._sync_weights(eng)
+        return eng
+
+    def _hot_tensors(self):
+        for layer in self.time_context_layers:
+            yield layer.linear.weight
+            yield layer.linear.bias
+            if layer.batch_norm:
+                yield layer.norm.weight
+                yield layer.norm.bias
+                yield layer.norm.running_mean
+                yield layer.norm.running_var
+        for lin in (self.segment_layer6, self.segment_layer7, self.output):
+            yield lin.weight
+            yield lin.bias
+
+    def _sync_weights(self, eng: _Engine):
+        """(Re)pack parameters into the engine when any of them changed (load_state_dict,
+        .to(), in-place edits bump tensor._version)."""
+        sig = tuple((t.data_ptr(), t._version) for t in self._hot_tensors())
+        if sig == eng.signature:
+            return
+        dev = eng.device
+        s = _stream_ptr(dev)
+
+        def ptr(t):
+            if t.device != dev or t.dtype != torch.float32:
+                raise RuntimeError(f"parameter on {t.device}/{t.dtype}; move the model to {dev} as float32 first")
+            return t.detach().contiguous().data_ptr()
+
+        keep = []   # contiguous() temporaries must outlive the enqueued pack kernels
+        for i, layer in enumerate(self.time_context_layers):
+            ts = [layer.linear.weight, layer.linear.bias]
+            if layer.batch_norm:
+                ts += [layer.norm.weight, layer.norm.bias, layer.norm.running_mean, layer.norm.running_var]
+                eps = layer.norm.eps
+            else:
+                eps = 0.0
+            cs = [t.detach().contiguous() for t in ts]
+            keep += cs
+            for t in cs:
+                if t.device != dev or t.dtype != torch.float32:
+                    raise RuntimeError(f"parameter on {t.device}/{t.dtype}; move the model to {dev} as float32")
+            p = [t.data_ptr() for t in cs] + [None] * (6 - len(cs))
+            _hip.check(_hip.lib.xvec_load_tdnn(eng.h, i, p[0], p[1], p[2], p[3], p[4], p[5], eps, s))
+        for which, lin in ((_hip.SEG6, self.segment_layer6), (_hip.SEG7, self.segment_layer7),
+                           (_hip.OUTPUT, self.output)):
+            _hip.check(_hip.lib.xvec_load_affine(eng.h, which, ptr(lin.weight), ptr(lin.bias), s))
+        torch.cuda.current_stream(dev).synchronize()   # packing done before temporaries die
+        del keep
+        eng.signature = sig
+
+    def _prep_input(self, x: torch.Tensor, what: str) -> torch.Tensor:
+        _require_gpu(x, what)
+        self._check_mode()
+        if x.dim() != 3:
+            raise ValueError(f"{what}: expected x[B,T,C], got shape {tuple(x.shape)}")
+        if x.shape[0] < 1:
+            raise ValueError(f"{what}: empty batch")
+        return x.detach().float().contiguous()
+
+    @staticmethod
+    def _lengths_arg(lengths, B, T):
+        if lengths is None:
+            return None, None
+        if torch.is_tensor(lengths):
+            lengths = lengths.detach().cpu().tolist()
+        lengths = [int(v) for v in lengths]
+        if len(lengths) != B:
+            raise ValueError(f"lengths has {len(lengths)} entries for a batch of {B}")
+        arr = (C.c_int32 * B)(*lengths)
+        return arr, lengths
+
+    def _run(self, x: torch.Tensor, mode: int, lengths=None) -> torch.Tensor:
+        x = self._prep_input(x, "XVectorModel")
+        B, T, Cin = x.shape
+        if Cin != self.hparams["input_size"]:
+            raise ValueError(f"expected {self.hparams['input_size']} input channels, got {Cin}")
+        if T <= TOTAL_CONTEXT:
+            raise ValueError(f"T={T}: the TDNN stack consumes {TOTAL_CONTEXT} frames of context; need T >= 15 "
+                             "(the reference silently returns empty/NaN tensors here)")
+        arr, lens = self._lengths_arg(lengths, B, T)
+        if lens is not None and (min(lens) <= TOTAL_CONTEXT or max(lens) > T):
+            raise ValueError(f"lengths must lie in [15, T={T}]")
+        eng = self._engine(x.device)
+        total = sum(lens) if lens is not None else B * T
+        ws, ws_bytes = eng.ensure_workspace(total, B)
+        n_out = self.hparams["num_classes"] if mode == _hip.MODE_LOGITS else self.hparams["x_vector_size"]
+        out = torch.empty((B, n_out), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _hip.check(_hip.lib.xvec_forward(eng.h, x.data_ptr(), arr, B, T, mode, _DTYPES[self.precision],
+                                             out.data_ptr(), ws, ws_bytes, _stream_ptr(x.device)))
+        return out
+
+    # ------------------------------------------------------------------ reference surface
+    def stat_pool(self, x, lengths=None):
+        """main.py:59-63: mean ‖ unbiased std over time, [B,T,C] -> [B,2C]."""
+        _require_gpu(x, "stat_pool")
+        if x.dim() != 3:
+            raise ValueError(f"stat_pool: expected x[B,T,C], got {tuple(x.shape)}")
+        x = x.detach().float().contiguous()
+        B, T, Cc = x.shape
+        out = torch.empty((B, 2 * Cc), dtype=torch.float32, device=x.device)
+        lp = None
+        if lengths is not None:
+            lt = torch.as_tensor(lengths, dtype=torch.int32, device=x.device).contiguous()
+            if lt.numel() != B:
+                raise ValueError("stat_pool: one length per utterance expected")
+            lp = lt.data_ptr()
+        with torch.cuda.device(x.device):
+            _hip.check(_hip.lib.xvec_stat_pool(x.data_ptr(), lp, B, T, Cc, out.data_ptr(), _stream_ptr(x.device)))
+        return out
+
+    def forward(self, x, lengths=None):
+        """main.py:66-75: logits [B, num_classes]."""
+        return self._run(x, _hip.MODE_LOGITS, lengths)
+
+    def extract_x_vec(self, x, lengths=None):
+        """main.py:81-94: x-vectors [B, x_vector_size] taken before the ReLU of
+        segment_layer6 (x_vec_extract_layer == 6 or any other value) or segment_layer7 (== 7)."""
+        mode = _hip.MODE_XVEC7 if self.x_vec_extract_layer == 7 else _hip.MODE_XVEC6
+        return self._run(x, mode, lengths)
+
+    def extract_packed(self, x_packed: torch.Tensor, offsets: Sequence[int], logits: bool = False):
+        """Ragged batch without padding: x_packed[sum(len), C], utterance i in rows
+        [offsets[i], offsets[i+1])."""
+        _require_gpu(x_packed, "extract_packed")
+        self._check_mode()
+        x = x_packed.detach().float().contiguous()
+        offs = [int(v) for v in offsets]
+        B = len(offs) - 1
+        if B < 1 or offs[0] != 0 or offs[-1] != x.shape[0] or x.dim() != 2:
+            raise ValueError("extract_packed: need x[sum(len),C] and offsets[0]=0, offsets[-1]=rows")
+        eng = self._engine(x.device)
+        ws, ws_bytes = eng.ensure_workspace(offs[-1], B)
+        mode = _hip.MODE_LOGITS if logits else (_hip.MODE_XVEC7 if self.x_vec_extract_layer == 7 else _hip.MODE_XVEC6)
+        n_out = self.hparams["num_classes"] if logits else self.hparams["x_vector_size"]
+        out = torch.empty((B, n_out), dtype=torch.float32, device=x.device)
+        arr = (C.c_int64 * (B + 1))(*offs)
+        with torch.cuda.device(x.device):
+            _hip.check(_hip.lib.xvec_forward_packed(eng.h, x.data_ptr(), arr, B, mode, _DTYPES[self.precision],
+                                                    out.data_ptr(), ws, ws_bytes, _stream_ptr(x.device)))
+        return out
+
+    # ------------------------------------------------------------------ per-stage entry points
+    def _tdnn_layer(self, index: int, x: torch.Tensor) -> torch.Tensor:
+        x = self._prep_input(x, "TdnnLayer")
+        B, T, _ = x.shape
+        layer = self.time_context_layers[index]
+        span = layer.context[-1] - layer.context[0]
+        if x.shape[2] != layer.input_size:
+            raise ValueError(f"TdnnLayer {index}: expected {layer.input_size} channels, got {x.shape[2]}")
+        if T <= span:
+            raise ValueError(f"TdnnLayer {index}: T={T} not longer than the context span {span}")
+        eng = self._engine(x.device)
+        ws, ws_bytes = eng.ensure_workspace(B * T, B)
+        y = torch.empty((B, T - span, layer.output_size), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _hip.check(_hip.lib.xvec_tdnn_layer(eng.h, index, x.data_ptr(), B, T, _DTYPES[self.precision],
+                                                y.data_ptr(), ws, ws_bytes, _stream_ptr(x.device)))
+        return y
+
+    def affine(self, which: str, x: torch.Tensor, relu: bool = False) -> torch.Tensor:
+        """segment_layer6 / segment_layer7 / output as a stand-alone HIP GEMM (+ReLU)."""
+        ids = {"segment_layer6": _hip.SEG6, "segment_layer7": _hip.SEG7, "output": _hip.OUTPUT}
+        _require_gpu(x, "affine")
+        self._check_mode()
+        x = x.detach().float().contiguous()
+        lin = getattr(self, which)
+        if x.dim() != 2 or x.shape[1] != lin.in_features:
+            raise ValueError(f"{which}: expected [M,{lin.in_features}], got {tuple(x.shape)}")
+        eng = self._engine(x.device)
+        y = torch.empty((x.shape[0], lin.out_features), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _hip.check(_hip.lib.xvec_affine(eng.h, ids[which], x.data_ptr(), x.shape[0], int(relu), y.data_ptr(),
+                                            _stream_ptr(x.device)))
+        return y
+
+    # ------------------------------------------------------------------ measurement
+    def set_profiling(self, on: bool, device=None):
+        dev = torch.device(device) if device is not None else next(self.parameters()).device
+        eng = self._engine(dev)
+        _hip.check(_hip.lib.xvec_set_profiling(eng.h, int(on)))
+
+    def timings_ms(self, device=None) -> dict:
+        dev = torch.device(device) if device is not None else next(self.parameters()).device
+        eng = self._engine(dev)
+        buf = (C.c_float * 16)()
+        n = C.c_int(0)
+        _hip.check(_hip.lib.xvec_get_timings(eng.h, buf, C.byref(n)))
+        return {name: float(buf[i]) for i, name in enumerate(_hip.TIMING_NAMES[:n.value])}
+
+    # ------------------------------------------------------------------ caller shims (main.py:135-146)
+    def test_step(self, batch, batch_index=0):
+        """Same I/O as the reference's Lightning hook: casts to fp32, returns
+        [(x_vecs, labels, ids)]."""
+        samples, labels, ids = batch
+        return [(self.extract_x_vec(samples.float()), labels, ids)]

@@ -1,0 +1,82 @@
+import ctypes
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+
+
+def assert_parity(got, ref, tol=1e-4, what=""):
+    """The path's tolerance (BASELINE north_star: 1e-4 relative fp32): per-row
+    norm-wise relative error <= tol AND allclose(rtol=tol, atol=tol*mean|ref|).  Element-wise
+    relative error alone is ill-conditioned: the reference differs from itself by 9e-3 on
+    near-zero components across batch sizes."""
+    got = torch.as_tensor(np.asarray(got) if not torch.is_tensor(got) else got).double().cpu()
+    ref = torch.as_tensor(np.asarray(ref) if not torch.is_tensor(ref) else ref).double().cpu()
+    assert got.shape == ref.shape, f"{what}: shape {tuple(got.shape)} vs {tuple(ref.shape)}"
+    assert torch.isfinite(got).all(), f"{what}: non-finite values"
+    g2, r2 = got.reshape(-1, got.shape[-1]), ref.reshape(-1, ref.shape[-1])
+    rel = (g2 - r2).norm(dim=1) / r2.norm(dim=1).clamp_min(1e-30)
+    assert rel.max().item() <= tol, f"{what}: row-wise relative error {rel.max().item():.3e} > {tol}"
+    atol = tol * ref.abs().mean().item()
+    bad = (got - ref).abs() > (atol + tol * ref.abs())
+    assert not bad.any(), f"{what}: {int(bad.sum())} elements outside rtol={tol}, atol={atol:.3e}"
+
+
+@pytest.fixture(scope="session")
+def synth():
+    import xvector_amd
+    return xvector_amd.synth
+
+
+@pytest.fixture(scope="session")
+def sd42(synth):
+    """Full-width synthetic weights, seed 42 (the ones the golden fixtures were made with)."""
+    return {k: torch.from_numpy(np.asarray(v)) for k, v in synth.make_state_dict(seed=42).items()}
+
+
+def float_params(sd):
+    return {k: v for k, v in sd.items() if v.is_floating_point()}
+
+
+@pytest.fixture(scope="session")
+def c_oracle():
+    path = os.path.join(ROOT, "oracle", "libxvec_oracle.so")
+    if not os.path.exists(path):
+        import subprocess
+        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True)
+    lib = ctypes.CDLL(path)
+    fp, ip = ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int)
+    lib.xvo_tdnn_layer.argtypes = [fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, fp, fp, fp, fp, fp, fp,
+                                   ctypes.c_float, ip, ctypes.c_int, ctypes.c_int, fp]
+    lib.xvo_stat_pool.argtypes = [fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, fp]
+    lib.xvo_linear.argtypes = [fp, ctypes.c_int, ctypes.c_int, fp, fp, ctypes.c_int, ctypes.c_int, fp]
+    for f in (lib.xvo_tdnn_layer, lib.xvo_stat_pool, lib.xvo_linear):
+        f.restype = None
+    return lib
+
+
+@pytest.fixture(scope="session")
+def gpu_model(sd42):
+    """Full-width XVectorModel on cuda:0 with the seed-42 weights."""
+    import xvector_amd as xa
+    assert torch.cuda.is_available(), "gpu tests need a HIP device"
+    m = xa.XVectorModel()
+    m.load_state_dict(sd42)
+    return m.to("cuda:0").eval()

@@ -1,0 +1,235 @@
+"""Parity of the HIP path (through the C ABI) with the oracle and the golden vectors.
+Run on the MI355X box: python -m pytest tests -m gpu."""
+import numpy as np
+import pytest
+import torch
+
+import xvector_oracle as oracle
+from conftest import assert_parity, float_params, load_golden
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _gpu(a):
+    return torch.as_tensor(np.asarray(a)).to(DEV)
+
+
+def test_library_is_the_native_one():
+    from xvector_amd import hip
+    assert "gfx950" in hip.version()
+    assert torch.cuda.get_device_properties(0).gcnArchName.startswith("gfx950")
+
+
+# ------------------------------------------------------------------------------- per layer
+def test_g2_tdnn_layers_vs_golden(gpu_model, synth):
+    """TdnnLayer.forward for each of the five layer shapes (tdnn_layer.py:26-41)."""
+    g = load_golden("g2_layers.npz")
+    h = _gpu(synth.make_mfcc(int(g["B"]), int(g["T"]), seed=int(g["seed_x"])))
+    for i, layer in enumerate(gpu_model.time_context_layers):
+        h = layer(h)
+        assert list(h.shape) == g[f"l{i}_shape"].tolist()
+        assert_parity(h[:, g[f"l{i}_frames"].tolist(), :], g[f"l{i}_rows"], 1e-4, f"layer {i} rows")
+        assert_parity(h.double().sum(dim=(0, 1))[None], g[f"l{i}_sum"][None], 1e-4, f"layer {i} sums")
+
+
+@pytest.mark.parametrize("layer,B,T", [(0, 2, 15), (0, 5, 131), (1, 3, 129), (2, 1, 300), (3, 7, 37), (4, 2, 150)])
+def test_tdnn_layer_vs_oracle_every_element(gpu_model, sd42, layer, B, T):
+    """Whole-tensor check against the fp64 oracle at sizes that straddle tile edges
+    (T not a multiple of anything, B*T below/above one 128-row tile)."""
+    p64 = oracle.cast_params(float_params(sd42), torch.float64)
+    cin = 24 if layer == 0 else 512
+    x = torch.from_numpy(np.random.default_rng(100 + layer).standard_normal((B, T, cin), dtype=np.float32))
+    ref = oracle.tdnn_layer(x.double(), p64, f"time_context_layers.{layer}.", oracle.CONTEXTS[layer])
+    got = gpu_model.time_context_layers[layer](x.to(DEV))
+    assert_parity(got, ref, 1e-4, f"layer {layer} B={B} T={T}")
+
+
+# ------------------------------------------------------------------------------- pooling
+def test_g3_stat_pool_vs_golden(gpu_model):
+    g = load_golden("g3_stat_pool.npz")
+    rng = np.random.default_rng(int(g["seed"]))
+    x = (rng.standard_normal((4, 286, 1500)) * float(g["scale"]) + float(g["shift"])).astype(np.float32)
+    assert_parity(gpu_model.stat_pool(_gpu(x)), g["pool_286"], 1e-4, "pool 286")
+    for n in (2, 3):
+        assert_parity(gpu_model.stat_pool(_gpu(np.ascontiguousarray(x[:, :n, :64]))), g[f"pool_{n}"], 1e-4, f"pool {n}")
+
+
+def test_stat_pool_edge_cases(gpu_model):
+    rng = np.random.default_rng(5)
+    # n == 1 -> NaN std, finite mean (torch.std semantics)
+    one = gpu_model.stat_pool(_gpu(rng.standard_normal((3, 1, 10), dtype=np.float32))).cpu()
+    assert torch.isnan(one[:, 10:]).all() and torch.isfinite(one[:, :10]).all()
+    # |mean| >> std: the shifted/Chan formulation must not cancel catastrophically
+    x = (1000.0 + 0.01 * rng.standard_normal((2, 286, 1500))).astype(np.float32)
+    ref = oracle.stat_pool(torch.from_numpy(x).double())
+    assert_parity(gpu_model.stat_pool(_gpu(x)), ref, 2e-3, "ill-conditioned pool")   # fp32 input rounding dominates
+    # constant column -> std exactly 0, not NaN
+    c = gpu_model.stat_pool(torch.full((1, 50, 8), 3.25, device=DEV)).cpu()
+    assert torch.equal(c[:, 8:], torch.zeros(1, 8)) and torch.equal(c[:, :8], torch.full((1, 8), 3.25))
+    # odd channel count (scalar-load kernel) and a length mask
+    x = rng.standard_normal((3, 40, 7), dtype=np.float32)
+    lens = [40, 2, 17]
+    ref = torch.cat([oracle.stat_pool(torch.from_numpy(x[i:i + 1, :n]).double()) for i, n in enumerate(lens)])
+    assert_parity(gpu_model.stat_pool(_gpu(x), lengths=lens), ref, 1e-4, "masked pool")
+
+
+# ------------------------------------------------------------------------------- affines
+@pytest.mark.parametrize("M", [1, 5, 32, 33, 256])
+def test_affine_layers(gpu_model, sd42, M):
+    p64 = oracle.cast_params(float_params(sd42), torch.float64)
+    rng = np.random.default_rng(M)
+    for name, K in (("segment_layer6", 3000), ("segment_layer7", 512), ("output", 512)):
+        x = torch.from_numpy(rng.standard_normal((M, K), dtype=np.float32))
+        ref = x.double() @ p64[name + ".weight"].t() + p64[name + ".bias"]
+        assert_parity(gpu_model.affine(name, x.to(DEV)), ref, 1e-4, f"{name} M={M}")
+        assert_parity(gpu_model.affine(name, x.to(DEV), relu=True), torch.relu(ref), 1e-4, f"{name} relu M={M}")
+
+
+# ------------------------------------------------------------------------------- whole path
+@pytest.mark.parametrize("B,T", [(1, 299), (8, 299), (1, 300), (8, 300)])
+def test_g4_full_path_vs_golden(sd42, synth, B, T):
+    import xvector_amd as xa
+    g = load_golden("g4_full.npz")
+    key = f"B{B}_T{T}"
+    x = _gpu(synth.make_mfcc(B, T, seed=int(g[key + "_seed_x"])))
+    m6 = xa.XVectorModel()
+    m6.load_state_dict(sd42)
+    m6 = m6.to(DEV)
+    assert_parity(m6.extract_x_vec(x), g[key + "_xvec6"], 1e-4, "xvec6")
+    assert_parity(m6(x), g[key + "_logits"], 1e-4, "logits")
+    m6.x_vec_extract_layer = 7
+    assert_parity(m6.extract_x_vec(x), g[key + "_xvec7"], 1e-4, "xvec7")
+    m6.x_vec_extract_layer = 3          # "any other value behaves as 6" (main.py:91-92)
+    assert_parity(m6.extract_x_vec(x), g[key + "_xvec6"], 1e-4, "xvec default branch")
+
+
+def test_g5_ragged_vs_golden(gpu_model, synth):
+    """Padded batch + lengths == the reference run per utterance on the un-padded slice."""
+    g = load_golden("g5_ragged.npz")
+    lens = g["lengths"].tolist()
+    x = synth.make_mfcc(3, 1000, seed=int(g["seed_x"]))
+    for i, n in enumerate(lens):           # poison the padding: it must not leak
+        x[i, n:] = np.nan
+    assert_parity(gpu_model.extract_x_vec(_gpu(x), lengths=lens), g["xvec6"], 1e-4, "ragged xvec6")
+    assert_parity(gpu_model(_gpu(x), lengths=lens), g["logits"], 1e-4, "ragged logits")
+    # packed entry point, same utterances without any padding
+    packed = np.concatenate([x[i, :n] for i, n in enumerate(lens)])
+    offs = np.concatenate([[0], np.cumsum(lens)]).tolist()
+    assert_parity(gpu_model.extract_packed(_gpu(packed), offs), g["xvec6"], 1e-4, "packed xvec6")
+
+
+@pytest.mark.parametrize("tag", ["bn", "nobn"])
+def test_g6_tiny_model(synth, tag):
+    """Reduced-width model (hidden 32, x-vector 16, 10 classes): exercises channel padding
+    of every layer and the batch_norm=False constructor path."""
+    import xvector_amd as xa
+    g = load_golden("g6_tiny.npz")
+    bn = tag == "bn"
+    if bn:
+        sd = {k[len("bn/w/"):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("bn/w/")}
+    else:
+        sd = {k: torch.from_numpy(np.asarray(v)) for k, v in synth.make_state_dict(
+            seed=int(g["nobn/seed_w"]), input_size=24, hidden_size=32, num_classes=10, x_vector_size=16,
+            batch_norm=False).items()}
+    m = xa.XVectorModel(input_size=24, hidden_size=32, num_classes=10, x_vector_size=16, batch_norm=bn)
+    m.load_state_dict(sd)
+    m = m.to(DEV)
+    x = _gpu(g[f"{tag}/x"])
+    assert_parity(m.extract_x_vec(x), g[f"{tag}/xvec6"], 1e-4, "tiny xvec6")
+    assert_parity(m(x), g[f"{tag}/logits"], 1e-4, "tiny logits")
+    m.x_vec_extract_layer = 7
+    assert_parity(m.extract_x_vec(x), g[f"{tag}/xvec7"], 1e-4, "tiny xvec7")
+    h = x
+    for layer in m.time_context_layers:
+        h = layer(h)
+    assert_parity(h[:, g[f"{tag}/frames_t"].tolist()], g[f"{tag}/frames"], 1e-4, "tiny frames")
+
+
+def test_g7_caller_contract(gpu_model, synth):
+    """test_step / test_epoch_end I/O (main.py:135-146): float64 loader output is cast to
+    fp32, rows keep input order, vectors are widened exactly to float64."""
+    from xvector_amd import extract
+    g = load_golden("g7_caller.npz")
+    xs = torch.from_numpy(synth.make_mfcc(5, 299, seed=int(g["seed_x"]))).double()
+    labels = torch.from_numpy(g["labels"])
+    ids = g["ids"].tolist()
+    recs = extract.extract_x_vectors(gpu_model, [(xs, labels, ids)])
+    assert [r[0] for r in recs] == g["out_ids"].tolist()
+    assert [r[1] for r in recs] == g["out_labels"].tolist()
+    vecs = np.stack([r[2] for r in recs])
+    assert vecs.dtype == np.float64
+    assert np.array_equal(vecs, vecs.astype(np.float32).astype(np.float64))      # exact widening
+    assert_parity(vecs, g["out_vecs"], 1e-4, "caller vectors")
+
+
+def test_odd_input_width_and_short_utterances(synth):
+    """input_size not a multiple of 4 (row padding kernel) and the shortest legal T=15
+    (one pooled frame -> NaN std in the reference too)."""
+    import xvector_amd as xa
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in synth.make_state_dict(
+        seed=8, input_size=13, hidden_size=40, num_classes=7, x_vector_size=12).items()}
+    m = xa.XVectorModel(input_size=13, hidden_size=40, num_classes=7, x_vector_size=12)
+    m.load_state_dict(sd)
+    m = m.to(DEV)
+    p64 = oracle.cast_params(float_params(sd), torch.float64)
+    x = torch.from_numpy(np.random.default_rng(3).standard_normal((3, 77, 13), dtype=np.float32))
+    assert_parity(m.extract_x_vec(x.to(DEV)), oracle.extract_x_vec(x.double(), p64), 1e-4, "odd widths")
+    x16 = x[:, :16]
+    assert_parity(m.extract_x_vec(x16.to(DEV)), oracle.extract_x_vec(x16.double(), p64), 1e-4, "T=16")
+    out15 = m.extract_x_vec(x[:, :15].to(DEV))
+    assert torch.isnan(out15).all()                         # std of one frame is NaN (reference: same)
+    with pytest.raises(ValueError):
+        m.extract_x_vec(x[:, :14].to(DEV))
+
+
+# ------------------------------------------------------------------------------- full size
+def test_full_size_properties(gpu_model, sd42, synth):
+    """BASELINE config 1 size (B=256, T=300): size-independent properties + sampled rows
+    against the oracle."""
+    x = _gpu(synth.make_mfcc(256, 300, seed=0))
+    out = gpu_model.extract_x_vec(x)
+    assert out.shape == (256, 512) and torch.isfinite(out).all()
+    # determinism: bit-identical on repeat (no atomics / fixed reduction order)
+    assert torch.equal(out, gpu_model.extract_x_vec(x))
+    # utterance independence: a row does not depend on its batch neighbours
+    perm = torch.randperm(256, generator=torch.Generator().manual_seed(1)).to(DEV)
+    assert_parity(gpu_model.extract_x_vec(x[perm]), out[perm], 1e-5, "permutation equivariance")
+    assert_parity(gpu_model.extract_x_vec(x[37:38]), out[37:38], 1e-5, "batch-of-one")
+    # sampled utterances against the fp32 oracle (what the reference computes)
+    idx = [0, 1, 127, 128, 255]
+    with torch.no_grad():
+        ref = oracle.extract_x_vec(x[idx].cpu(), float_params(sd42))
+    assert_parity(out[idx], ref, 1e-4, "sampled rows")
+
+
+def test_full_size_ragged(gpu_model, sd42, synth):
+    """BASELINE config 2 (B=256, 200..1000 frames): masked result == per-utterance result."""
+    lens = synth.make_lengths(256)
+    T = int(lens.max())
+    x = synth.make_mfcc(256, T, seed=2)
+    out = gpu_model.extract_x_vec(_gpu(x), lengths=lens.tolist())
+    assert torch.isfinite(out).all()
+    for i in (0, 100, 255, int(lens.argmin()), int(lens.argmax())):
+        n = int(lens[i])
+        alone = gpu_model.extract_x_vec(_gpu(x[i:i + 1, :n]))
+        assert_parity(out[i:i + 1], alone, 1e-5, f"utt {i} len {n}")
+    i = int(lens.argmin())
+    with torch.no_grad():
+        ref = oracle.extract_x_vec(torch.from_numpy(x[i:i + 1, :int(lens[i])]), float_params(sd42))
+    assert_parity(out[i:i + 1], ref, 1e-4, "shortest vs oracle")
+
+
+def test_errors_are_loud(gpu_model):
+    with pytest.raises(RuntimeError):
+        gpu_model.extract_x_vec(torch.zeros(1, 300, 24))           # CPU tensor: no fallback
+    with pytest.raises(ValueError):
+        gpu_model.extract_x_vec(torch.zeros(1, 300, 23, device=DEV))
+    with pytest.raises(ValueError):
+        gpu_model.extract_x_vec(torch.zeros(2, 300, 24, device=DEV), lengths=[300, 10])
+    gpu_model.train()
+    try:
+        with pytest.raises(RuntimeError):
+            gpu_model(torch.zeros(1, 300, 24, device=DEV))
+    finally:
+        gpu_model.eval()

@@ -20,11 +20,23 @@
 // column mean and M2 (sum of squared deviations about that mean) of the valid frames are
 // written to a small partials buffer; pool_finalize merges them (Chan et al.), so the
 // [frames, 1500] activation of layer 5 never goes to HBM.
+#include <cstdlib>
+
 #include "xvec_internal.h"
 
 namespace xvec {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#ifdef XVEC_DIAG
+// Diagnostic build only (make DIAG=1): per-phase s_memtime sums of wave 0 of every block.
+__device__ unsigned long long g_diag[8 * 8192];
+#define DIAG_STAMP(var) unsigned long long var; { __builtin_amdgcn_sched_barrier(0); var = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); }
+#define DIAG_ADD(acc_, t1_, t0_) acc_ += (t1_) - (t0_);
+#else
+#define DIAG_STAMP(var)
+#define DIAG_ADD(acc_, t1_, t0_)
+#endif
 
 template <int BM, int BN>
 struct TileCfg {
@@ -47,6 +59,7 @@ __global__ __launch_bounds__(256, 2) void tdnn_f32_kernel(const TdnnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int kStage = TileCfg<BM, BN>::kStageFloats;
 
+    DIAG_STAMP(t_entry)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -132,46 +145,118 @@ __global__ __launch_bounds__(256, 2) void tdnn_f32_kernel(const TdnnArgs a) {
     XVEC_MFMA4(A0.y, A1.y, B0.y, B1.y)                                                               \
     XVEC_MFMA4(A0.z, A1.z, B0.z, B1.z)                                                               \
     XVEC_MFMA4(A0.w, A1.w, B0.w, B1.w)
-    // fragments of k-group q+1 are fetched from LDS while the 16 MFMAs of group q run
-#define XVEC_COMPUTE_CHUNK(buf_)                                                                     \
-    {                                                                                                \
-        const float* S = smem + (buf_) * kStage;                                                     \
-        float4 pa0, pa1, pb0, pb1, qa0, qa1, qb0, qb1;                                               \
-        XVEC_LOAD_FRAGS(0, pa0, pa1, pb0, pb1)                                                       \
-        XVEC_LOAD_FRAGS(1, qa0, qa1, qb0, qb1)                                                       \
-        XVEC_MFMA16(pa0, pa1, pb0, pb1)                                                              \
-        XVEC_LOAD_FRAGS(2, pa0, pa1, pb0, pb1)                                                       \
-        XVEC_MFMA16(qa0, qa1, qb0, qb1)                                                              \
-        XVEC_LOAD_FRAGS(3, qa0, qa1, qb0, qb1)                                                       \
-        XVEC_MFMA16(pa0, pa1, pb0, pb1)                                                              \
-        XVEC_MFMA16(qa0, qa1, qb0, qb1)                                                              \
-    }
 #define XVEC_MFMA4(a0_, a1_, b0_, b1_)                                                               \
     acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0_, b0_, acc[0][0], 0, 0, 0);                  \
     acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0_, b1_, acc[0][1], 0, 0, 0);                  \
     acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1_, b0_, acc[1][0], 0, 0, 0);                  \
     acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1_, b1_, acc[1][1], 0, 0, 0);
 
+    // Software pipeline.  Per K-chunk a wave issues four groups of 16 MFMAs (k-groups q0..q3,
+    // 64 cycles of matrix pipe each).  Every other instruction of the chunk is slotted BETWEEN
+    // MFMAs so the pipe never waits for the wave's memory instructions (in-kernel stamps showed
+    // ~450 cycles for a burst of 8 ds_write_b128 and ~500 for 8 global loads + 4 ds_reads):
+    //   q0: fragment reads of q1, then the 8 LDS stores of chunk it+1 (2 per 4 MFMAs)
+    //   q1: fragment reads of q2, then the 8 global loads of chunk it+2 (2 per 4 MFMAs)
+    //   q2: fragment reads of q3, MFMAs, block barrier (chunk it+1 is now visible, chunk it's
+    //       buffer is free)
+    //   q3: first fragment read of chunk it+1 under the last 16 MFMAs of chunk it
+#define SB() __builtin_amdgcn_sched_barrier(0)
+#define XVEC_GLOAD_A(dst_, j_, tap_, kc_)                                                            \
+    {                                                                                                \
+        const int64_t row_shift = (int64_t)(tap_) * a.tap_rows;                                      \
+        const int kbase = (kc_) * kBK;                                                               \
+        const float* xp = xrow + row_shift * a.ldx + kbase;                                          \
+        XVEC_LOAD_A(dst_, j_)                                                                        \
+    }
+#define XVEC_GLOAD_B(dst_, j_, it_) dst_ = *reinterpret_cast<const float4*>(wrow + (it_) * kBK + (int64_t)(32 * (j_)) * a.k_pad);
+#define XVEC_LSTORE(buf_, off_, v_) *reinterpret_cast<float4*>(smem + (buf_) * kStage + st_off + (off_)) = v_;
+#define XVEC_FRAG(dst_, base_, q_) dst_ = *reinterpret_cast<const float4*>(S + (base_) + ((((2 * (q_) + h) ^ sw)) << 2));
+    // one MFMA followed by one "slot" statement that issues in its 64-cycle shadow
+#define XVEC_M(i_, n_, av_, bv_, slot_)                                                              \
+    acc[i_][n_] = __builtin_amdgcn_mfma_f32_32x32x2f32(av_, bv_, acc[i_][n_], 0, 0, 0);              \
+    SB();                                                                                            \
+    slot_;                                                                                           \
+    SB();
+    // 16 MFMAs of one k-group (fragments A0,A1,B0,B1) with 16 slots
+#define XVEC_GROUP(A0, A1, B0, B1, s0, s1, s2, s3, s4, s5, s6, s7, s8, s9, s10, s11, s12, s13, s14, s15) \
+    XVEC_M(0, 0, A0.x, B0.x, s0) XVEC_M(0, 1, A0.x, B1.x, s1) XVEC_M(1, 0, A1.x, B0.x, s2) XVEC_M(1, 1, A1.x, B1.x, s3)   \
+    XVEC_M(0, 0, A0.y, B0.y, s4) XVEC_M(0, 1, A0.y, B1.y, s5) XVEC_M(1, 0, A1.y, B0.y, s6) XVEC_M(1, 1, A1.y, B1.y, s7)   \
+    XVEC_M(0, 0, A0.z, B0.z, s8) XVEC_M(0, 1, A0.z, B1.z, s9) XVEC_M(1, 0, A1.z, B0.z, s10) XVEC_M(1, 1, A1.z, B1.z, s11) \
+    XVEC_M(0, 0, A0.w, B0.w, s12) XVEC_M(0, 1, A0.w, B1.w, s13) XVEC_M(1, 0, A1.w, B0.w, s14) XVEC_M(1, 1, A1.w, B1.w, s15)
+#define NOP_ (void)0
+    // one K-chunk; WRITE: chunk it+1 exists (store it, barrier, prefetch its q0 fragments);
+    // LOAD: chunk it+2 exists (fetch it into the staging registers)
+#define XVEC_CHUNK_BODY(it_, WRITE, LOAD)                                                            \
+    {                                                                                                \
+        const float* S = smem + ((it_) & 1) * kStage;                                                \
+        const int nb = ((it_) + 1) & 1;                                                              \
+        const int a1_base = a_base + 32 * kBK, b1_base = b_base + 32 * kBK;                          \
+        XVEC_GROUP(pa0, pa1, pb0, pb1,                                                               \
+                   XVEC_FRAG(qa0, a_base, 1), XVEC_FRAG(qa1, a1_base, 1), XVEC_FRAG(qb0, b_base, 1), \
+                   XVEC_FRAG(qb1, b1_base, 1),                                                       \
+                   if (WRITE) { XVEC_LSTORE(nb, 0, ra0) }, if (WRITE) { XVEC_LSTORE(nb, 32 * kBK, ra1) },            \
+                   if (WRITE) { XVEC_LSTORE(nb, 64 * kBK, ra2) }, if (WRITE) { XVEC_LSTORE(nb, 96 * kBK, ra3) },     \
+                   if (WRITE) { XVEC_LSTORE(nb, BM * kBK, rb0) }, if (WRITE) { XVEC_LSTORE(nb, BM * kBK + 32 * kBK, rb1) }, \
+                   if (WRITE) { XVEC_LSTORE(nb, BM * kBK + 64 * kBK, rb2) },                         \
+                   if (WRITE) { XVEC_LSTORE(nb, BM * kBK + 96 * kBK, rb3) },                         \
+                   NOP_, NOP_, NOP_, if (LOAD) { if (++kc == a.cpt) { kc = 0; ++tap; } })            \
+        XVEC_GROUP(qa0, qa1, qb0, qb1,                                                               \
+                   XVEC_FRAG(pa0, a_base, 2), XVEC_FRAG(pa1, a1_base, 2), XVEC_FRAG(pb0, b_base, 2), \
+                   XVEC_FRAG(pb1, b1_base, 2),                                                       \
+                   if (LOAD) XVEC_GLOAD_A(ra0, 0, tap, kc), if (LOAD) XVEC_GLOAD_A(ra1, 1, tap, kc), \
+                   if (LOAD) XVEC_GLOAD_A(ra2, 2, tap, kc), if (LOAD) XVEC_GLOAD_A(ra3, 3, tap, kc), \
+                   if (LOAD) { XVEC_GLOAD_B(rb0, 0, (it_) + 2) }, if (LOAD) { XVEC_GLOAD_B(rb1, 1, (it_) + 2) },     \
+                   if (LOAD) { XVEC_GLOAD_B(rb2, 2, (it_) + 2) }, if (LOAD) { XVEC_GLOAD_B(rb3, 3, (it_) + 2) },     \
+                   NOP_, NOP_, NOP_, NOP_)                                                           \
+        XVEC_GROUP(pa0, pa1, pb0, pb1,                                                               \
+                   XVEC_FRAG(qa0, a_base, 3), XVEC_FRAG(qa1, a1_base, 3), XVEC_FRAG(qb0, b_base, 3), \
+                   XVEC_FRAG(qb1, b1_base, 3),                                                       \
+                   NOP_, NOP_, NOP_, NOP_, NOP_, NOP_, NOP_, NOP_, NOP_, NOP_, NOP_, NOP_)           \
+        if (WRITE) {                                                                                 \
+            __syncthreads();                                                                         \
+            S = smem + nb * kStage;                                                                  \
+        }                                                                                            \
+        XVEC_GROUP(qa0, qa1, qb0, qb1,                                                               \
+                   if (WRITE) { XVEC_FRAG(pa0, a_base, 0) }, if (WRITE) { XVEC_FRAG(pa1, a1_base, 0) },              \
+                   if (WRITE) { XVEC_FRAG(pb0, b_base, 0) }, if (WRITE) { XVEC_FRAG(pb1, b1_base, 0) },              \
+                   NOP_, NOP_, NOP_, NOP_, NOP_, NOP_, NOP_, NOP_, NOP_, NOP_, NOP_, NOP_)           \
+    }
+
+    float4 pa0, pa1, pb0, pb1, qa0, qa1, qb0, qb1;
+    int tap = 0, kc = 0;
     XVEC_LOAD_CHUNK(0, 0, 0)
     XVEC_STORE_CHUNK(0)
     __syncthreads();
-
-    // steady state: chunk `it` is in LDS buffer it&1; fetch it+1 while computing it
-    int tap = 0, kc = 0;
-    for (int it = 0; it + 1 < n_chunks; ++it) {
-        if (++kc == a.cpt) { kc = 0; ++tap; }
-        XVEC_LOAD_CHUNK(tap, kc, it + 1)
-        __builtin_amdgcn_sched_barrier(0);   // keep the global loads ahead of the MFMA block
-        XVEC_COMPUTE_CHUNK(it & 1)
-        __builtin_amdgcn_sched_barrier(0);
-        XVEC_STORE_CHUNK((it + 1) & 1)
-        __syncthreads();
+    {
+        const float* S = smem;
+        XVEC_LOAD_FRAGS(0, pa0, pa1, pb0, pb1)
     }
-    XVEC_COMPUTE_CHUNK((n_chunks - 1) & 1)
+    if (n_chunks > 1) {
+        if (++kc == a.cpt) { kc = 0; ++tap; }
+        XVEC_LOAD_CHUNK(tap, kc, 1)
+    }
+    SB();
+    DIAG_STAMP(t_loop0)
+    int it = 0;
+    for (; it + 2 < n_chunks; ++it) XVEC_CHUNK_BODY(it, true, true)
+    if (it + 1 < n_chunks) {
+        XVEC_CHUNK_BODY(it, true, false)
+        ++it;
+    }
+    XVEC_CHUNK_BODY(it, false, false)
+    DIAG_STAMP(t_loop1)
+#undef SB
+#undef XVEC_M
+#undef XVEC_GROUP
+#undef XVEC_FRAG
+#undef NOP_
+#undef XVEC_GLOAD_A
+#undef XVEC_GLOAD_B
+#undef XVEC_LSTORE
+#undef XVEC_CHUNK_BODY
 #undef XVEC_LOAD_CHUNK
 #undef XVEC_LOAD_A
 #undef XVEC_STORE_CHUNK
-#undef XVEC_COMPUTE_CHUNK
 #undef XVEC_MFMA4
 #undef XVEC_MFMA16
 #undef XVEC_LOAD_FRAGS
@@ -255,6 +340,17 @@ __global__ __launch_bounds__(256, 2) void tdnn_f32_kernel(const TdnnArgs a) {
             }
         }
     }
+#ifdef XVEC_DIAG
+    {
+        __builtin_amdgcn_s_waitcnt(0);   // epilogue stores retired
+        DIAG_STAMP(t_exit)
+        if (tid == 0 && blockIdx.x < 8192) {
+            unsigned long long* d = g_diag + blockIdx.x * 8;
+            d[0] = t_loop0 - t_entry; d[1] = t_loop1 - t_loop0; d[2] = t_exit - t_loop1; d[3] = t_entry;
+            d[4] = t_exit; d[5] = n_chunks; d[6] = __builtin_amdgcn_s_getreg(0xF814) ; d[7] = 0;
+        }
+    }
+#endif
 }
 
 template <bool GUARD, bool POOL, bool STORE>
@@ -262,18 +358,27 @@ static hipError_t launch_variant(const TdnnArgs& a, hipStream_t s) {
     constexpr int BM = 128, BN = 128;
     auto kern = tdnn_f32_kernel<BM, BN, GUARD, POOL, STORE>;
     static bool attr_set = false;   // per-variant; benign if raced (idempotent)
+    static int lds_pad = 0;
     if (!attr_set) {
+        const char* e_pad = getenv("XVEC_LDS_PAD");   // experiment knob: extra LDS to cap blocks/CU
+        lds_pad = e_pad ? atoi(e_pad) : 0;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           TileCfg<BM, BN>::kLdsBytes);
+                                           TileCfg<BM, BN>::kLdsBytes + lds_pad);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     const int grid = a.m_tiles * a.n_tiles;
-    constexpr int lds_bytes = TileCfg<BM, BN>::kLdsBytes;
+    const int lds_bytes = TileCfg<BM, BN>::kLdsBytes + lds_pad;
     kern<<<dim3(grid), dim3(256), lds_bytes, s>>>(a);
     return hipGetLastError();
 }
+
+#ifdef XVEC_DIAG
+extern "C" int xvec_diag_read(unsigned long long* host, int n_words) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_diag), (size_t)n_words * 8);
+}
+#endif
 
 hipError_t launch_tdnn_f32(const TdnnArgs& a, bool guard_a, bool fuse_pool, bool store_y, hipStream_t s) {
     if (fuse_pool) {

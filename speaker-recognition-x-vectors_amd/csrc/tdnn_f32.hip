@@ -5,21 +5,32 @@
 // (the reference's torch.cat, tdnn_layer.py:29) is ever materialised: a K-chunk that
 // belongs to tap j is staged from rows p + j*dil of the same activation buffer.
 //
-// Machine mapping (CDNA4): 256 threads = 4 wave64 in a 2x2 grid, block tile 128 frames x
-// 128 channels, each wave 64x64 as 2x2 v_mfma_f32_32x32x2_f32 tiles (64 accumulator
-// VGPRs).  K is consumed in 32-wide chunks, register-staged global -> LDS (double
-// buffered, one barrier per chunk, next chunk's global loads issued before the MFMAs of
-// the current one).  LDS rows are 128 B with a 16-B-chunk XOR swizzle so the ds_read_b128
-// fragment reads are bank-conflict free.  Each ds_read_b128 feeds four MFMAs: lane half
-// h of the wave owns k = 8q+4h..8q+4h+3 of every 8-wide k group, for A and B alike, so
-// the products pair up correctly (the k order inside a chunk is permuted, which fp32
-// addition tolerates to within rounding).
+// Machine mapping (CDNA4)
+//   * persistent grid: 2 blocks per CU (64 KiB LDS each).  The output is cut into columns of
+//     128 channels; the frames of one column are split, at 32-row granularity, into equal
+//     contiguous ranges, one per block, so the last wave of work is ~1 % of the launch
+//     instead of a partial round of fixed 128x128 tiles.  A block walks its range in tiles of
+//     up to 4 row groups (128 frames); the blocks that cover the same frames for the different
+//     channel columns get consecutive ids on one XCD, so the activation rows are shared in
+//     that XCD's L2.
+//   * 256 threads = 4 wave64; wave w owns channels [32w, 32w+32) of the tile for all its
+//     frames: G accumulators of v_mfma_f32_32x32x2_f32 (<= 64 VGPRs).
+//   * K is consumed in 32-wide chunks: global -> registers -> LDS (two LDS buffers, two
+//     register sets, so a chunk's global loads are issued ~1.5 chunks before they are
+//     stored), one block barrier per chunk.  LDS rows are 128 B with a 16-B-chunk XOR
+//     swizzle: the ds_read_b128 fragment reads are bank-conflict free.
+//   * each ds_read_b128 feeds four MFMAs: lane half h owns k = 8q+4h..8q+4h+3 of every
+//     8-wide k group, for A and B alike, so the products pair up (the k order inside a chunk
+//     is permuted, which fp32 addition tolerates to rounding).
+//   * every memory instruction of a chunk is slotted behind one MFMA (64 pipe cycles each):
+//     in-kernel stamps showed bursts of 8 ds_write_b128 / 8 global loads idling the matrix
+//     pipe for ~450 cycles each; spread out they are free.
 //
-// Epilogue: bias + ReLU + folded BatchNorm in registers; optional fused statistics
-// pooling (main.py:59-63): per 64-row wave sub-tile and per utterance overlapping it, the
-// column mean and M2 (sum of squared deviations about that mean) of the valid frames are
-// written to a small partials buffer; pool_finalize merges them (Chan et al.), so the
-// [frames, 1500] activation of layer 5 never goes to HBM.
+// Epilogue: bias + ReLU + folded BatchNorm in registers; optional fused statistics pooling
+// (main.py:59-63): per 32-row group and per utterance overlapping it, the column mean and
+// M2 (sum of squared deviations about that mean) of the valid frames go to a small partials
+// buffer that pool_finalize merges (Chan et al.), so the [frames,1500] activation of layer 5
+// never goes to HBM.
 #include <cstdlib>
 
 #include "xvec_internal.h"
@@ -28,348 +39,321 @@ namespace xvec {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+constexpr int kBM = 128, kBN = 128;
+constexpr int kStageFloats = (kBM + kBN) * kBK;   // one LDS buffer: A tile then B tile
+constexpr int kLdsBytes = 2 * kStageFloats * 4;
+
 #ifdef XVEC_DIAG
-// Diagnostic build only (make DIAG=1): per-phase s_memtime sums of wave 0 of every block.
+// Diagnostic build only (make DIAG=1): s_memtime stamps of wave 0 of every block.
 __device__ unsigned long long g_diag[8 * 8192];
-#define DIAG_STAMP(var) unsigned long long var; { __builtin_amdgcn_sched_barrier(0); var = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); }
-#define DIAG_ADD(acc_, t1_, t0_) acc_ += (t1_) - (t0_);
-#else
-#define DIAG_STAMP(var)
-#define DIAG_ADD(acc_, t1_, t0_)
 #endif
 
-template <int BM, int BN>
-struct TileCfg {
-    static constexpr int kThreads = 256;
-    static constexpr int kStageFloats = (BM + BN) * kBK;
-    static constexpr int kLdsBytes = 2 * kStageFloats * 4;
-};
+#define SB() __builtin_amdgcn_sched_barrier(0)
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     // blocks b, b+8, b+16.. share an XCD (round-robin dispatch); give each XCD a
-    // contiguous run of tiles so neighbours share A rows / W columns in its L2.
+    // contiguous run of logical ids (bijective for any nwg).
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, local = bid >> 3;
     const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return base + local;
 }
 
-template <int BM, int BN, bool GUARD, bool POOL, bool STORE>
-__global__ __launch_bounds__(256, 2) void tdnn_f32_kernel(const TdnnArgs a) {
-    static_assert(BM == 128 && BN == 128, "wave layout below assumes a 128x128 tile");
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int kStage = TileCfg<BM, BN>::kStageFloats;
+// Fused statistics-pooling partial (main.py:59-63) of one 32-row group held in one accumulator:
+// for every utterance overlapping flat rows [row_g, row_g+32), the mean and M2 (sum of squared
+// deviations about that mean) of this lane's column over the utterance's valid pooled frames.
+__device__ __forceinline__ void pool_group(const TdnnArgs& a, const f32x16& v, int64_t row_g, int h, int col) {
+    int u;
+    if (a.offsets == nullptr) {
+        u = (int)(row_g / a.fixed_T);
+    } else {
+        int lo = 0, hi = a.n_utts;            // largest u with offsets[u] <= row_g
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (a.offsets[mid] <= row_g) lo = mid; else hi = mid;
+        }
+        u = lo;
+    }
+    const int64_t grp = row_g >> 5;
+    for (; u < a.n_utts; ++u) {
+        const int64_t off = a.offsets ? a.offsets[u] : (int64_t)u * a.fixed_T;
+        if (off >= row_g + 32) break;
+        const int64_t len = a.offsets ? (a.offsets[u + 1] - off) : (int64_t)a.fixed_T;
+        const int64_t lo_r = off > row_g ? off : row_g;
+        int64_t hi_r = off + len - a.shrink;
+        if (hi_r > row_g + 32) hi_r = row_g + 32;
+        if (hi_r <= lo_r) continue;
+        const int lo_l = (int)(lo_r - row_g), hi_l = (int)(hi_r - row_g);   // local rows [lo_l, hi_l)
+        const float inv_cnt = 1.f / (float)(hi_l - lo_l);
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int lr = (e & 3) + 8 * (e >> 2) + 4 * h;
+            s += (lr >= lo_l && lr < hi_l) ? v[e] : 0.f;
+        }
+        s += __shfl_xor(s, 32);
+        const float mean = s * inv_cnt;
+        float m2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int lr = (e & 3) + 8 * (e >> 2) + 4 * h;
+            const float d = v[e] - mean;
+            m2 += (lr >= lo_l && lr < hi_l) ? d * d : 0.f;
+        }
+        m2 += __shfl_xor(m2, 32);
+        if (h == 0) {
+            float* part = a.pool_part + (grp + u) * (int64_t)(2 * a.ldy);
+            part[col] = mean;
+            part[a.ldy + col] = m2;
+        }
+    }
+}
 
-    DIAG_STAMP(t_entry)
+// Per-thread state of one tile walk.  Global reads go through raw buffer loads: a block-uniform
+// descriptor per operand (rebased at the tile origin), a uniform scalar byte offset (tap row
+// shift, row group, chunk column) and ONE 32-bit per-thread byte offset per operand, so no
+// per-load 64-bit address is ever computed or kept in VGPRs.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+struct Ctx {
+    __amdgpu_buffer_rsrc_t xrsrc;   // X + m0*ldx
+    __amdgpu_buffer_rsrc_t wrsrc;   // W + n0*k_pad
+    int x_toff;          // (r0*ldx + c*4) * 4 bytes  (per thread)
+    int w_toff;          // (r0*k_pad + c*4) * 4 bytes
+    int64_t m0;          // first flat row of the tile
+    int tap, kc, itl;    // next chunk to fetch: (tap, kc) and its linear index
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
+    // uniform by construction (kernel argument + blockIdx-derived offset); readfirstlane makes
+    // that provable so hipcc emits no waterfall loop around the buffer loads
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    void* q = reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo);
+    return __builtin_amdgcn_make_buffer_rsrc(q, (short)0, 0x7fffffff, 0x00020000);
+}
+
+__device__ __forceinline__ float4 buf_load16(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff) {
+    // (whole-vector bit cast: __builtin_bit_cast on single elements of the result made hipcc
+    // 7.2 narrow the load to one dword and splat it)
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0);
+    const f32x4 f = __builtin_bit_cast(f32x4, v);
+    return make_float4(f.x, f.y, f.z, f.w);
+}
+
+// step to the next K-chunk; past the last one it stays put, so the (unused) look-ahead loads of
+// the final chunks re-read the last chunk instead of needing their own code path
+__device__ __forceinline__ void advance(const TdnnArgs& a, Ctx& cx, int n_chunks) {
+    if (cx.itl + 1 < n_chunks) {
+        ++cx.itl;
+        if (++cx.kc == a.cpt) {
+            cx.kc = 0;
+            ++cx.tap;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The main loop is written with token-pasting macros over NAMED registers (sA<i>_<set>,
+// fa<i>_<fset>, acc<i>): register arrays, even with compile-time indices through inlined
+// lambdas, were left in scratch memory by hipcc (ROCm 7.2) once scheduling barriers were present.
+// G (row groups of the tile, 1..4) is a template parameter; ops of absent groups vanish.
+// ---------------------------------------------------------------------------------------------
+#define XV_KO(q_) ((((2 * (q_)) + h) ^ sw) << 2)
+// fragment reads (LDS -> VGPR) of k-group q_ into fragment set f_ from buffer base S_
+#define XV_FRG_A(i_, q_, f_, S_) \
+    if constexpr (G > i_) { fa##i_##_##f_ = *reinterpret_cast<const float4*>((S_) + a_rd + i_ * 32 * kBK + XV_KO(q_)); }
+#define XV_FRG_B(q_, f_, S_) fb_##f_ = *reinterpret_cast<const float4*>((S_) + b_rd + XV_KO(q_));
+// LDS stores of staging set n_ into LDS buffer n_
+#define XV_LST_A(i_, n_) \
+    if constexpr (G > i_) { *reinterpret_cast<float4*>(smem + n_ * kStageFloats + st_off + i_ * 32 * kBK) = sA##i_##_##n_; }
+#define XV_LST_B(j_, n_) \
+    *reinterpret_cast<float4*>(smem + n_ * kStageFloats + st_off + kBM * kBK + j_ * 32 * kBK) = sB##j_##_##n_;
+// global loads of the chunk cx points at into staging set n_
+#define XV_GLD_A(i_, n_)                                                                                  \
+    if constexpr (G > i_) {                                                                               \
+        const int row_shift = cx.tap * a.tap_rows;                                                        \
+        const int soff = ((row_shift + 32 * i_) * a.ldx + cx.kc * kBK) * 4;                               \
+        if (GUARD) {                                                                                      \
+            const bool ok = (cx.m0 + r0 + 32 * i_ + row_shift < a.x_rows) && (cx.kc * kBK + c * 4 < a.kpt); \
+            const float4 t = buf_load16(cx.xrsrc, ok ? cx.x_toff : 0, ok ? soff : 0);                     \
+            sA##i_##_##n_ = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);                                     \
+        } else {                                                                                          \
+            sA##i_##_##n_ = buf_load16(cx.xrsrc, cx.x_toff, soff);                                        \
+        }                                                                                                 \
+    }
+#define XV_GLD_B(j_, n_)                                                                                  \
+    {                                                                                                     \
+        sB##j_##_##n_ = buf_load16(cx.wrsrc, cx.w_toff, (32 * j_ * a.k_pad + cx.itl * kBK) * 4);          \
+    }
+#define XV_GLD_ALL(n_) XV_GLD_A(0, n_) XV_GLD_A(1, n_) XV_GLD_A(2, n_) XV_GLD_A(3, n_) \
+                       XV_GLD_B(0, n_) XV_GLD_B(1, n_) XV_GLD_B(2, n_) XV_GLD_B(3, n_)
+#define XV_LST_ALL(n_) XV_LST_A(0, n_) XV_LST_A(1, n_) XV_LST_A(2, n_) XV_LST_A(3, n_) \
+                       XV_LST_B(0, n_) XV_LST_B(1, n_) XV_LST_B(2, n_) XV_LST_B(3, n_)
+// one MFMA (row group i_, k component c_, fragment set f_) and the statement slotted behind it
+#define XV_MF(i_, c_, f_, slot_)                                                                          \
+    if constexpr (G > i_) {                                                                               \
+        acc##i_ = __builtin_amdgcn_mfma_f32_32x32x2f32(fa##i_##_##f_.c_, fb_##f_.c_, acc##i_, 0, 0, 0);   \
+    }                                                                                                     \
+    SB();                                                                                                 \
+    slot_                                                                                                 \
+    SB();
+// one k-group: 4 components x 4 row groups, 16 slots
+#define XV_KG(f_, s0, s1, s2, s3, s4, s5, s6, s7, s8, s9, s10, s11, s12, s13, s14, s15)                   \
+    XV_MF(0, x, f_, s0) XV_MF(1, x, f_, s1) XV_MF(2, x, f_, s2) XV_MF(3, x, f_, s3)                       \
+    XV_MF(0, y, f_, s4) XV_MF(1, y, f_, s5) XV_MF(2, y, f_, s6) XV_MF(3, y, f_, s7)                       \
+    XV_MF(0, z, f_, s8) XV_MF(1, z, f_, s9) XV_MF(2, z, f_, s10) XV_MF(3, z, f_, s11)                     \
+    XV_MF(0, w, f_, s12) XV_MF(1, w, f_, s13) XV_MF(2, w, f_, s14) XV_MF(3, w, f_, s15)
+#define XV_NOP ;
+// One K-chunk held in LDS buffer P_; N_ = the other buffer = the staging set holding chunk it+1.
+// Branch-free: the last chunk of a tile also stores/loads/reads ahead (clamped to the last
+// chunk, results unused) -- n_chunks is even, so the two-chunk loop body needs no tail variants.
+#define XV_CHUNK(P_, N_)                                                                                  \
+    {                                                                                                     \
+        const float* S = smem + P_ * kStageFloats;                                                        \
+        const float* Sn = smem + N_ * kStageFloats;                                                       \
+        XV_KG(0, XV_FRG_A(0, 1, 1, S), XV_FRG_A(1, 1, 1, S), XV_FRG_A(2, 1, 1, S), XV_FRG_A(3, 1, 1, S),  \
+              XV_FRG_B(1, 1, S),                                                                          \
+              XV_LST_A(0, N_), XV_LST_A(1, N_), XV_LST_A(2, N_), XV_LST_A(3, N_),                         \
+              XV_LST_B(0, N_), XV_LST_B(1, N_), XV_LST_B(2, N_), XV_LST_B(3, N_),                         \
+              XV_NOP, XV_NOP, advance(a, cx, n_chunks);)                                                  \
+        XV_KG(1, XV_FRG_A(0, 2, 0, S), XV_FRG_A(1, 2, 0, S), XV_FRG_A(2, 2, 0, S), XV_FRG_A(3, 2, 0, S),  \
+              XV_FRG_B(2, 0, S),                                                                          \
+              XV_GLD_A(0, N_), XV_GLD_A(1, N_), XV_GLD_A(2, N_), XV_GLD_A(3, N_),                         \
+              XV_GLD_B(0, N_), XV_GLD_B(1, N_), XV_GLD_B(2, N_), XV_GLD_B(3, N_),                         \
+              XV_NOP, XV_NOP, XV_NOP)                                                                     \
+        XV_KG(0, XV_FRG_A(0, 3, 1, S), XV_FRG_A(1, 3, 1, S), XV_FRG_A(2, 3, 1, S), XV_FRG_A(3, 3, 1, S),  \
+              XV_FRG_B(3, 1, S), XV_NOP, XV_NOP, XV_NOP, XV_NOP, XV_NOP, XV_NOP, XV_NOP, XV_NOP, XV_NOP,  \
+              XV_NOP, XV_NOP)                                                                             \
+        __syncthreads(); /* chunk it+1 complete in LDS; chunk it's buffer is free */                     \
+        XV_KG(1, XV_FRG_A(0, 0, 0, Sn), XV_FRG_A(1, 0, 0, Sn), XV_FRG_A(2, 0, 0, Sn),                     \
+              XV_FRG_A(3, 0, 0, Sn), XV_FRG_B(0, 0, Sn), XV_NOP, XV_NOP, XV_NOP,                          \
+              XV_NOP, XV_NOP, XV_NOP, XV_NOP, XV_NOP, XV_NOP, XV_NOP, XV_NOP)                             \
+    }
+
+// One tile of G row groups (32 frames each) x 128 channels, starting at row group g0.
+template <int G, bool GUARD, bool POOL, bool STORE>
+__device__ __forceinline__ void process_tile(const TdnnArgs& a, float* smem, int64_t g0, int n0) {
     const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-
-    const int wg = xcd_remap(blockIdx.x, gridDim.x);
-    const int n_tile = wg % a.n_tiles;
-    const int m_tile = wg / a.n_tiles;
-    const int64_t m0 = (int64_t)m_tile * BM;
-    const int n0 = n_tile * BN;
-
-    // ---- staging map: thread -> (row r0 + 32*j, 16-byte chunk c) of the 32-wide K chunk
-    const int c = tid & 7;
-    const int r0 = tid >> 3;
-    const int st_off = r0 * kBK + ((c ^ ((r0 >> 1) & 7)) << 2);   // + 32*j*kBK per j
-    const float* __restrict__ xrow = a.X + (m0 + r0) * (int64_t)a.ldx + c * 4;
-    const float* __restrict__ wrow = a.W + (int64_t)(n0 + r0) * a.k_pad + c * 4;
+    // staging map: thread -> (row r0 + 32*j, 16-byte chunk c) of a 32-wide K chunk
+    const int c = tid & 7, r0 = tid >> 3;
+    const int st_off = r0 * kBK + ((c ^ ((r0 >> 1) & 7)) << 2);
+    // fragment read map: row (base + r), logical 16-B chunk 2q+h, swizzled by row
+    const int sw = (r >> 1) & 7;
+    const int a_rd = r * kBK;
+    const int b_rd = kBM * kBK + (wave * 32 + r) * kBK;
     const int n_chunks = a.n_taps * a.cpt;
 
-    // staging registers: named scalars, not arrays (arrays indexed in unrolled loops were left
-    // in scratch by hipcc once scheduling barriers were added).
-    float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+    Ctx cx;
+    cx.m0 = g0 * 32;
+    cx.xrsrc = make_rsrc(a.X + cx.m0 * (int64_t)a.ldx);
+    cx.wrsrc = make_rsrc(a.W + (int64_t)n0 * a.k_pad);
+    cx.x_toff = (r0 * a.ldx + c * 4) * 4;
+    cx.w_toff = (r0 * a.k_pad + c * 4) * 4;
+    cx.tap = 0;
+    cx.kc = 0;
+    cx.itl = 0;
 
-#define XVEC_LOAD_A(dst_, j_)                                                                        \
-    if (GUARD) {                                                                                     \
-        const bool ok = (m0 + r0 + 32 * (j_) + row_shift < a.x_rows) && (kbase + c * 4 < a.kpt);     \
-        dst_ = ok ? *reinterpret_cast<const float4*>(xp + (int64_t)(32 * (j_)) * a.ldx)              \
-                  : make_float4(0.f, 0.f, 0.f, 0.f);                                                 \
-    } else {                                                                                         \
-        dst_ = *reinterpret_cast<const float4*>(xp + (int64_t)(32 * (j_)) * a.ldx);                  \
-    }
-    // global -> registers for K-chunk (tap, kc)
-#define XVEC_LOAD_CHUNK(tap_, kc_, it_)                                                              \
-    {                                                                                                \
-        const int64_t row_shift = (int64_t)(tap_) * a.tap_rows;                                      \
-        const int kbase = (kc_) * kBK;                                                               \
-        const float* xp = xrow + row_shift * a.ldx + kbase;                                          \
-        const float* wp = wrow + (it_) * kBK;                                                        \
-        XVEC_LOAD_A(ra0, 0) XVEC_LOAD_A(ra1, 1) XVEC_LOAD_A(ra2, 2) XVEC_LOAD_A(ra3, 3)              \
-        rb0 = *reinterpret_cast<const float4*>(wp);                                                  \
-        rb1 = *reinterpret_cast<const float4*>(wp + (int64_t)32 * a.k_pad);                          \
-        rb2 = *reinterpret_cast<const float4*>(wp + (int64_t)64 * a.k_pad);                          \
-        rb3 = *reinterpret_cast<const float4*>(wp + (int64_t)96 * a.k_pad);                          \
-    }
-#define XVEC_STORE_CHUNK(buf_)                                                                       \
-    {                                                                                                \
-        float* As_ = smem + (buf_) * kStage + st_off;                                                \
-        float* Bs_ = As_ + BM * kBK;                                                                 \
-        *reinterpret_cast<float4*>(As_) = ra0;                                                       \
-        *reinterpret_cast<float4*>(As_ + 32 * kBK) = ra1;                                            \
-        *reinterpret_cast<float4*>(As_ + 64 * kBK) = ra2;                                            \
-        *reinterpret_cast<float4*>(As_ + 96 * kBK) = ra3;                                            \
-        *reinterpret_cast<float4*>(Bs_) = rb0;                                                       \
-        *reinterpret_cast<float4*>(Bs_ + 32 * kBK) = rb1;                                            \
-        *reinterpret_cast<float4*>(Bs_ + 64 * kBK) = rb2;                                            \
-        *reinterpret_cast<float4*>(Bs_ + 96 * kBK) = rb3;                                            \
-    }
-
-    f32x16 acc[2][2];
+    // two staging sets (_0/_1): A row groups 0..3 and W row blocks 0..3; two fragment sets
+    float4 sA0_0, sA1_0, sA2_0, sA3_0, sB0_0, sB1_0, sB2_0, sB3_0;
+    float4 sA0_1, sA1_1, sA2_1, sA3_1, sB0_1, sB1_1, sB2_1, sB3_1;
+    float4 fa0_0, fa1_0, fa2_0, fa3_0, fb_0, fa0_1, fa1_1, fa2_1, fa3_1, fb_1;
+    f32x16 acc0, acc1, acc2, acc3;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int n = 0; n < 2; ++n)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][n][e] = 0.f;
+    for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; acc2[e] = 0.f; acc3[e] = 0.f; }
 
-    // fragment read offsets (floats): row (base + r), logical 16-B chunk 2q+h, swizzled
-    const int sw = (r >> 1) & 7;
-    const int a_base = (wm * 64 + r) * kBK;
-    const int b_base = BM * kBK + (wn * 64 + r) * kBK;
-
-#define XVEC_LOAD_FRAGS(q_, A0, A1, B0, B1)                                                          \
-    {                                                                                                \
-        const int ko = (((2 * (q_) + h) ^ sw) << 2);                                                 \
-        A0 = *reinterpret_cast<const float4*>(S + a_base + ko);                                      \
-        A1 = *reinterpret_cast<const float4*>(S + a_base + 32 * kBK + ko);                           \
-        B0 = *reinterpret_cast<const float4*>(S + b_base + ko);                                      \
-        B1 = *reinterpret_cast<const float4*>(S + b_base + 32 * kBK + ko);                           \
-    }
-#define XVEC_MFMA16(A0, A1, B0, B1)                                                                  \
-    XVEC_MFMA4(A0.x, A1.x, B0.x, B1.x)                                                               \
-    XVEC_MFMA4(A0.y, A1.y, B0.y, B1.y)                                                               \
-    XVEC_MFMA4(A0.z, A1.z, B0.z, B1.z)                                                               \
-    XVEC_MFMA4(A0.w, A1.w, B0.w, B1.w)
-#define XVEC_MFMA4(a0_, a1_, b0_, b1_)                                                               \
-    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0_, b0_, acc[0][0], 0, 0, 0);                  \
-    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0_, b1_, acc[0][1], 0, 0, 0);                  \
-    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1_, b0_, acc[1][0], 0, 0, 0);                  \
-    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1_, b1_, acc[1][1], 0, 0, 0);
-
-    // Software pipeline.  Per K-chunk a wave issues four groups of 16 MFMAs (k-groups q0..q3,
-    // 64 cycles of matrix pipe each).  Every other instruction of the chunk is slotted BETWEEN
-    // MFMAs so the pipe never waits for the wave's memory instructions (in-kernel stamps showed
-    // ~450 cycles for a burst of 8 ds_write_b128 and ~500 for 8 global loads + 4 ds_reads):
-    //   q0: fragment reads of q1, then the 8 LDS stores of chunk it+1 (2 per 4 MFMAs)
-    //   q1: fragment reads of q2, then the 8 global loads of chunk it+2 (2 per 4 MFMAs)
-    //   q2: fragment reads of q3, MFMAs, block barrier (chunk it+1 is now visible, chunk it's
-    //       buffer is free)
-    //   q3: first fragment read of chunk it+1 under the last 16 MFMAs of chunk it
-#define SB() __builtin_amdgcn_sched_barrier(0)
-#define XVEC_GLOAD_A(dst_, j_, tap_, kc_)                                                            \
-    {                                                                                                \
-        const int64_t row_shift = (int64_t)(tap_) * a.tap_rows;                                      \
-        const int kbase = (kc_) * kBK;                                                               \
-        const float* xp = xrow + row_shift * a.ldx + kbase;                                          \
-        XVEC_LOAD_A(dst_, j_)                                                                        \
-    }
-#define XVEC_GLOAD_B(dst_, j_, it_) dst_ = *reinterpret_cast<const float4*>(wrow + (it_) * kBK + (int64_t)(32 * (j_)) * a.k_pad);
-#define XVEC_LSTORE(buf_, off_, v_) *reinterpret_cast<float4*>(smem + (buf_) * kStage + st_off + (off_)) = v_;
-#define XVEC_FRAG(dst_, base_, q_) dst_ = *reinterpret_cast<const float4*>(S + (base_) + ((((2 * (q_) + h) ^ sw)) << 2));
-    // one MFMA followed by one "slot" statement that issues in its 64-cycle shadow
-#define XVEC_M(i_, n_, av_, bv_, slot_)                                                              \
-    acc[i_][n_] = __builtin_amdgcn_mfma_f32_32x32x2f32(av_, bv_, acc[i_][n_], 0, 0, 0);              \
-    SB();                                                                                            \
-    slot_;                                                                                           \
+    // ---- tile prologue: chunk 0 -> LDS buffer 0; chunks 1 and 2 in flight in the two sets
+    XV_GLD_ALL(0)
+    advance(a, cx, n_chunks);
+    XV_GLD_ALL(1)
     SB();
-    // 16 MFMAs of one k-group (fragments A0,A1,B0,B1) with 16 slots
-#define XVEC_GROUP(A0, A1, B0, B1, s0, s1, s2, s3, s4, s5, s6, s7, s8, s9, s10, s11, s12, s13, s14, s15) \
-    XVEC_M(0, 0, A0.x, B0.x, s0) XVEC_M(0, 1, A0.x, B1.x, s1) XVEC_M(1, 0, A1.x, B0.x, s2) XVEC_M(1, 1, A1.x, B1.x, s3)   \
-    XVEC_M(0, 0, A0.y, B0.y, s4) XVEC_M(0, 1, A0.y, B1.y, s5) XVEC_M(1, 0, A1.y, B0.y, s6) XVEC_M(1, 1, A1.y, B1.y, s7)   \
-    XVEC_M(0, 0, A0.z, B0.z, s8) XVEC_M(0, 1, A0.z, B1.z, s9) XVEC_M(1, 0, A1.z, B0.z, s10) XVEC_M(1, 1, A1.z, B1.z, s11) \
-    XVEC_M(0, 0, A0.w, B0.w, s12) XVEC_M(0, 1, A0.w, B1.w, s13) XVEC_M(1, 0, A1.w, B0.w, s14) XVEC_M(1, 1, A1.w, B1.w, s15)
-#define NOP_ (void)0
-    // one K-chunk; WRITE: chunk it+1 exists (store it, barrier, prefetch its q0 fragments);
-    // LOAD: chunk it+2 exists (fetch it into the staging registers)
-#define XVEC_CHUNK_BODY(it_, WRITE, LOAD)                                                            \
-    {                                                                                                \
-        const float* S = smem + ((it_) & 1) * kStage;                                                \
-        const int nb = ((it_) + 1) & 1;                                                              \
-        const int a1_base = a_base + 32 * kBK, b1_base = b_base + 32 * kBK;                          \
-        XVEC_GROUP(pa0, pa1, pb0, pb1,                                                               \
-                   XVEC_FRAG(qa0, a_base, 1), XVEC_FRAG(qa1, a1_base, 1), XVEC_FRAG(qb0, b_base, 1), \
-                   XVEC_FRAG(qb1, b1_base, 1),                                                       \
-                   if (WRITE) { XVEC_LSTORE(nb, 0, ra0) }, if (WRITE) { XVEC_LSTORE(nb, 32 * kBK, ra1) },            \
-                   if (WRITE) { XVEC_LSTORE(nb, 64 * kBK, ra2) }, if (WRITE) { XVEC_LSTORE(nb, 96 * kBK, ra3) },     \
-                   if (WRITE) { XVEC_LSTORE(nb, BM * kBK, rb0) }, if (WRITE) { XVEC_LSTORE(nb, BM * kBK + 32 * kBK, rb1) }, \
-                   if (WRITE) { XVEC_LSTORE(nb, BM * kBK + 64 * kBK, rb2) },                         \
-                   if (WRITE) { XVEC_LSTORE(nb, BM * kBK + 96 * kBK, rb3) },                         \
-                   NOP_, NOP_, NOP_, if (LOAD) { if (++kc == a.cpt) { kc = 0; ++tap; } })            \
-        XVEC_GROUP(qa0, qa1, qb0, qb1,                                                               \
-                   XVEC_FRAG(pa0, a_base, 2), XVEC_FRAG(pa1, a1_base, 2), XVEC_FRAG(pb0, b_base, 2), \
-                   XVEC_FRAG(pb1, b1_base, 2),                                                       \
-                   if (LOAD) XVEC_GLOAD_A(ra0, 0, tap, kc), if (LOAD) XVEC_GLOAD_A(ra1, 1, tap, kc), \
-                   if (LOAD) XVEC_GLOAD_A(ra2, 2, tap, kc), if (LOAD) XVEC_GLOAD_A(ra3, 3, tap, kc), \
-                   if (LOAD) { XVEC_GLOAD_B(rb0, 0, (it_) + 2) }, if (LOAD) { XVEC_GLOAD_B(rb1, 1, (it_) + 2) },     \
-                   if (LOAD) { XVEC_GLOAD_B(rb2, 2, (it_) + 2) }, if (LOAD) { XVEC_GLOAD_B(rb3, 3, (it_) + 2) },     \
-                   NOP_, NOP_, NOP_, NOP_)                                                           \
-        XVEC_GROUP(pa0, pa1, pb0, pb1,                                                               \
-                   XVEC_FRAG(qa0, a_base, 3), XVEC_FRAG(qa1, a1_base, 3), XVEC_FRAG(qb0, b_base, 3), \
-                   XVEC_FRAG(qb1, b1_base, 3),                                                       \
-                   NOP_, NOP_, NOP_, NOP_, NOP_, NOP_, NOP_, NOP_, NOP_, NOP_, NOP_, NOP_)           \
-        if (WRITE) {                                                                                 \
-            __syncthreads();                                                                         \
-            S = smem + nb * kStage;                                                                  \
-        }                                                                                            \
-        XVEC_GROUP(qa0, qa1, qb0, qb1,                                                               \
-                   if (WRITE) { XVEC_FRAG(pa0, a_base, 0) }, if (WRITE) { XVEC_FRAG(pa1, a1_base, 0) },              \
-                   if (WRITE) { XVEC_FRAG(pb0, b_base, 0) }, if (WRITE) { XVEC_FRAG(pb1, b1_base, 0) },              \
-                   NOP_, NOP_, NOP_, NOP_, NOP_, NOP_, NOP_, NOP_, NOP_, NOP_, NOP_, NOP_)           \
-    }
-
-    float4 pa0, pa1, pb0, pb1, qa0, qa1, qb0, qb1;
-    int tap = 0, kc = 0;
-    XVEC_LOAD_CHUNK(0, 0, 0)
-    XVEC_STORE_CHUNK(0)
+    XV_LST_ALL(0)
+    SB();
+    advance(a, cx, n_chunks);
+    XV_GLD_ALL(0)
     __syncthreads();
-    {
-        const float* S = smem;
-        XVEC_LOAD_FRAGS(0, pa0, pa1, pb0, pb1)
-    }
-    if (n_chunks > 1) {
-        if (++kc == a.cpt) { kc = 0; ++tap; }
-        XVEC_LOAD_CHUNK(tap, kc, 1)
-    }
+    XV_FRG_A(0, 0, 0, smem) XV_FRG_A(1, 0, 0, smem) XV_FRG_A(2, 0, 0, smem) XV_FRG_A(3, 0, 0, smem)
+    XV_FRG_B(0, 0, smem)
     SB();
-    DIAG_STAMP(t_loop0)
-    int it = 0;
-    for (; it + 2 < n_chunks; ++it) XVEC_CHUNK_BODY(it, true, true)
-    if (it + 1 < n_chunks) {
-        XVEC_CHUNK_BODY(it, true, false)
-        ++it;
-    }
-    XVEC_CHUNK_BODY(it, false, false)
-    DIAG_STAMP(t_loop1)
-#undef SB
-#undef XVEC_M
-#undef XVEC_GROUP
-#undef XVEC_FRAG
-#undef NOP_
-#undef XVEC_GLOAD_A
-#undef XVEC_GLOAD_B
-#undef XVEC_LSTORE
-#undef XVEC_CHUNK_BODY
-#undef XVEC_LOAD_CHUNK
-#undef XVEC_LOAD_A
-#undef XVEC_STORE_CHUNK
-#undef XVEC_MFMA4
-#undef XVEC_MFMA16
-#undef XVEC_LOAD_FRAGS
 
-    // ---- epilogue: bias + ReLU + folded BatchNorm (tdnn_layer.py:30-39) -----------------
+    // ---- main loop over K chunks, two per trip (LDS buffer 0 then 1); n_chunks is even
+    for (int it = 0; it < n_chunks; it += 2) {
+        XV_CHUNK(0, 1)
+        XV_CHUNK(1, 0)
+    }
+
+    // ---- epilogue: bias + ReLU + folded BatchNorm (tdnn_layer.py:30-39)
     // accumulator element e of lane (r, h): row = (e&3) + 8*(e>>2) + 4*h, col = r
-    const int64_t row_w = m0 + wm * 64;   // first flat row of this wave's sub-tile
-#pragma unroll
-    for (int n = 0; n < 2; ++n) {
-        const int col = n0 + wn * 64 + n * 32 + r;
-        const float bi = a.bias[col], sc = a.scale[col], sh = a.shift[col];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                float v = acc[i][n][e] + bi;
-                v = fmaxf(v, 0.f);
-                v = fmaf(v, sc, sh);
-                acc[i][n][e] = v;
-                if (STORE) {
-                    const int64_t row = row_w + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                    a.Y[row * a.ldy + col] = v;
-                }
-            }
-        }
+    const int col = n0 + wave * 32 + r;
+    const float bi = a.bias[col], sc = a.scale[col], sh = a.shift[col];
+#define XV_EPI(i_)                                                                                        \
+    if constexpr (G > i_) {                                                                               \
+        _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                                  \
+            float v = acc##i_[e] + bi;                                                                    \
+            v = fmaxf(v, 0.f);                                                                            \
+            v = fmaf(v, sc, sh);                                                                          \
+            acc##i_[e] = v;                                                                               \
+            if (STORE) {                                                                                  \
+                const int64_t row = cx.m0 + i_ * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;                     \
+                a.Y[row * a.ldy + col] = v;                                                               \
+            }                                                                                             \
+        }                                                                                                 \
+        if (POOL) pool_group(a, acc##i_, cx.m0 + i_ * 32, h, col);                                        \
     }
+    XV_EPI(0) XV_EPI(1) XV_EPI(2) XV_EPI(3)
+#undef XV_EPI
+    // the next tile's prologue overwrites LDS buffer 0: every wave must be done reading
+    __syncthreads();
+}
 
-    if (POOL) {
-        // ---- fused statistics pooling partials (main.py:59-63) --------------------------
-        // utterances overlapping flat rows [row_w, row_w + 64)
-        int u;
-        if (a.offsets == nullptr) {
-            u = (int)(row_w / a.fixed_T);
-        } else {
-            int lo = 0, hi = a.n_utts;              // largest u with offsets[u] <= row_w
-            while (hi - lo > 1) {
-                const int mid = (lo + hi) >> 1;
-                if (a.offsets[mid] <= row_w) lo = mid; else hi = mid;
-            }
-            u = lo;
-        }
-        const int64_t sub = row_w >> 6;
-        for (; u < a.n_utts; ++u) {
-            const int64_t off = a.offsets ? a.offsets[u] : (int64_t)u * a.fixed_T;
-            if (off >= row_w + 64) break;
-            const int64_t len = a.offsets ? (a.offsets[u + 1] - off) : (int64_t)a.fixed_T;
-            const int64_t lo_r = off > row_w ? off : row_w;
-            int64_t hi_r = off + len - a.shrink;
-            if (hi_r > row_w + 64) hi_r = row_w + 64;
-            if (hi_r <= lo_r) continue;
-            const int lo_l = (int)(lo_r - row_w), hi_l = (int)(hi_r - row_w);   // local rows [lo_l, hi_l)
-            const float inv_cnt = 1.f / (float)(hi_l - lo_l);
-            float* part = a.pool_part + (sub + u) * (int64_t)(2 * a.ldy);
-#pragma unroll
-            for (int n = 0; n < 2; ++n) {
-                float s = 0.f;
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int lr = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                        s += (lr >= lo_l && lr < hi_l) ? acc[i][n][e] : 0.f;
-                    }
-                s += __shfl_xor(s, 32);
-                const float mean = s * inv_cnt;
-                float m2 = 0.f;
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int lr = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                        const float d = acc[i][n][e] - mean;
-                        m2 += (lr >= lo_l && lr < hi_l) ? d * d : 0.f;
-                    }
-                m2 += __shfl_xor(m2, 32);
-                if (h == 0) {
-                    const int col = n0 + wn * 64 + n * 32 + r;
-                    part[col] = mean;
-                    part[a.ldy + col] = m2;
-                }
-            }
-        }
-    }
+template <bool GUARD, bool POOL, bool STORE>
+__global__ __launch_bounds__(256, 2) void tdnn_f32_kernel(const TdnnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
 #ifdef XVEC_DIAG
-    {
-        __builtin_amdgcn_s_waitcnt(0);   // epilogue stores retired
-        DIAG_STAMP(t_exit)
-        if (tid == 0 && blockIdx.x < 8192) {
-            unsigned long long* d = g_diag + blockIdx.x * 8;
-            d[0] = t_loop0 - t_entry; d[1] = t_loop1 - t_loop0; d[2] = t_exit - t_loop1; d[3] = t_entry;
-            d[4] = t_exit; d[5] = n_chunks; d[6] = __builtin_amdgcn_s_getreg(0xF814) ; d[7] = 0;
-        }
+    const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
+#endif
+    // logical id -> (row range p, channel column j); the n_tiles columns of one range are
+    // consecutive ids on one XCD
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int j = lid % a.n_tiles;
+    const int p = lid / a.n_tiles;
+    const int64_t g_begin = a.groups_total * (int64_t)p / a.blocks_per_col;
+    const int64_t g_end = a.groups_total * (int64_t)(p + 1) / a.blocks_per_col;
+    const int n0 = j * kBN;
+    int64_t g = g_begin;
+    for (; g + 4 <= g_end; g += 4) process_tile<4, GUARD, POOL, STORE>(a, smem, g, n0);
+    const int rem = (int)(g_end - g);
+    if (rem == 3) process_tile<3, GUARD, POOL, STORE>(a, smem, g, n0);
+    else if (rem == 2) process_tile<2, GUARD, POOL, STORE>(a, smem, g, n0);
+    else if (rem == 1) process_tile<1, GUARD, POOL, STORE>(a, smem, g, n0);
+#ifdef XVEC_DIAG
+    if (threadIdx.x == 0 && blockIdx.x < 8192) {
+        __builtin_amdgcn_s_waitcnt(0);
+        unsigned long long* d = g_diag + blockIdx.x * 8;
+        d[0] = t_entry;
+        d[1] = __builtin_amdgcn_s_memtime();
+        d[2] = (unsigned long long)(g_end - g_begin);
     }
 #endif
 }
 
 template <bool GUARD, bool POOL, bool STORE>
 static hipError_t launch_variant(const TdnnArgs& a, hipStream_t s) {
-    constexpr int BM = 128, BN = 128;
-    auto kern = tdnn_f32_kernel<BM, BN, GUARD, POOL, STORE>;
+    auto kern = tdnn_f32_kernel<GUARD, POOL, STORE>;
     static bool attr_set = false;   // per-variant; benign if raced (idempotent)
     static int lds_pad = 0;
     if (!attr_set) {
         const char* e_pad = getenv("XVEC_LDS_PAD");   // experiment knob: extra LDS to cap blocks/CU
         lds_pad = e_pad ? atoi(e_pad) : 0;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           TileCfg<BM, BN>::kLdsBytes + lds_pad);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes + lds_pad);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    const int grid = a.m_tiles * a.n_tiles;
-    const int lds_bytes = TileCfg<BM, BN>::kLdsBytes + lds_pad;
+    const int grid = a.blocks_per_col * a.n_tiles;
+    const int lds_bytes = kLdsBytes + lds_pad;
     kern<<<dim3(grid), dim3(256), lds_bytes, s>>>(a);
     return hipGetLastError();
 }
@@ -381,6 +365,8 @@ extern "C" int xvec_diag_read(unsigned long long* host, int n_words) {
 #endif
 
 hipError_t launch_tdnn_f32(const TdnnArgs& a, bool guard_a, bool fuse_pool, bool store_y, hipStream_t s) {
+    if (a.groups_total <= 0 || a.blocks_per_col <= 0 || a.blocks_per_col > a.groups_total)
+        return hipErrorInvalidValue;
     if (fuse_pool) {
         if (guard_a) return hipErrorInvalidValue;
         return store_y ? launch_variant<false, true, true>(a, s) : launch_variant<false, true, false>(a, s);

@@ -4,6 +4,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -56,6 +57,8 @@ struct xvec_handle {
     size_t offs_cap;
     hipEvent_t offs_evt;
     bool offs_pending;
+    int num_cu;
+    int blocks_per_cu;                 // persistent TDNN blocks per CU (LDS allows 2)
     // profiling
     bool profiling;
     hipEvent_t ev0[T_COUNT], ev1[T_COUNT];
@@ -83,7 +86,7 @@ Plan make_plan(const xvec_handle* h, int64_t total, int B) {
     p.actA = o;   o += align_up((size_t)p.rows_alloc * nh * 4);
     p.actB = o;   o += align_up((size_t)p.rows_alloc * nh * 4);
     p.act5 = o;   o += align_up((size_t)p.rows_alloc * n5 * 4);
-    p.part_slots = p.m_pad / 64 + B + 1;
+    p.part_slots = p.m_pad / 32 + B + 1;
     p.part = o;   o += align_up((size_t)p.part_slots * 2 * n5 * 4);
     p.pooled = o; o += align_up((size_t)B * 2 * XVEC_POOL_CHANNELS * 4);
     p.seg6 = o;   o += align_up((size_t)B * h->cfg.x_vector_size * 4);
@@ -109,15 +112,16 @@ void fill_geometry(xvec_handle* h) {
             const int ldx = (i == 0) ? h->cin_pad : hid;
             g.n_taps = 1;
             g.tap_rows = 0;
-            g.tap_stride_src = (kCtxLen[i] == 1) ? round_up(g.cin, kBK) : ldx;
+            g.tap_stride_src = (kCtxLen[i] == 1) ? round_up(g.cin, 2 * kBK) : ldx;
             g.kpt = (kCtxLen[i] == 1) ? g.cin : kCtxLen[i] * ldx;
         } else {
             g.n_taps = kCtxLen[i];
             g.tap_rows = kCtxDil[i];
             g.kpt = g.cin;
-            g.tap_stride_src = round_up(g.cin, kBK);
+            g.tap_stride_src = round_up(g.cin, 2 * kBK);
         }
-        g.kpt_pad = round_up(g.kpt, kBK);
+        // whole chunk PAIRS per tap: the kernel's main loop consumes two 32-wide chunks per trip
+        g.kpt_pad = round_up(g.kpt, 2 * kBK);
         g.k_pad = g.n_taps * g.kpt_pad;
     }
 }
@@ -160,14 +164,19 @@ int run_tdnn(xvec_handle* h, int layer, const float* X, int ldx, int64_t x_rows,
     a.kpt = g.kpt;
     a.cpt = g.kpt_pad / kBK;
     a.k_pad = g.k_pad;
-    a.m_tiles = (int)(p.m_pad / 128);
     a.n_tiles = g.n_pad / 128;
+    a.groups_total = (p.total + 31) / 32;
+    {
+        int64_t per_col = (int64_t)h->num_cu * h->blocks_per_cu / a.n_tiles;
+        if (per_col < 1) per_col = 1;
+        if (per_col > a.groups_total) per_col = a.groups_total;
+        a.blocks_per_col = (int)per_col;
+    }
     a.pool_part = part;
     a.offsets = offs_dev;
     a.n_utts = B;
     a.fixed_T = fixed_T;
     a.shrink = XVEC_TOTAL_CONTEXT;
-    if ((int64_t)a.m_tiles * a.n_tiles > 0x7fffffff) return fail(XVEC_ERR_ARG, "batch too large for one launch");
     StageTimer t(h, T_L1 + layer, s);
     HIP_TRY(launch_tdnn_f32(a, guard, fuse_pool, store_y, s));
     return XVEC_OK;
@@ -212,7 +221,7 @@ int forward_rows(xvec_handle* h, const float* x_rows, int ldx, const int64_t* of
         f.n_pad = h->geo[4].n_pad;
         f.fixed_T = fixed_T;
         f.shrink = XVEC_TOTAL_CONTEXT;
-        f.sub_rows = 64;
+        f.sub_rows = 32;
         HIP_TRY(launch_pool_finalize(f, s));
     }
     const int xv = h->cfg.x_vector_size, K6 = 2 * XVEC_POOL_CHANNELS;
@@ -296,6 +305,12 @@ int xvec_create(const xvec_cfg* cfg, xvec_handle** out) {
     if (!h) return fail(XVEC_ERR_STATE, "out of host memory");
     memset(h, 0, sizeof(*h));
     h->cfg = *cfg;
+    h->num_cu = prop.multiProcessorCount;
+    {
+        const char* e = getenv("XVEC_BLOCKS_PER_CU");   // experiment knob
+        h->blocks_per_cu = e ? atoi(e) : 2;
+        if (h->blocks_per_cu < 1) h->blocks_per_cu = 1;
+    }
     h->cin_pad = round_up(cfg->input_size, 4);
     fill_geometry(h);
     for (int i = 0; i < XVEC_NUM_TDNN; ++i) {

@@ -43,9 +43,11 @@ struct TdnnArgs {
     int ldx, ldy;
     int n_taps, tap_rows, kpt, cpt;   // cpt = chunks per tap = kpt_pad / kBK
     int k_pad;
-    int m_tiles, n_tiles;
+    int n_tiles;              // 128-channel columns
+    int blocks_per_col;       // persistent blocks per column; grid = n_tiles * blocks_per_col
+    int64_t groups_total;     // 32-row groups of the flat frame axis (ceil(rows / 32))
     // fused statistics-pooling epilogue (layer 5)
-    float* pool_part;         // [slots][2][n_pad] (mean, M2) per (64-row sub-tile, utterance)
+    float* pool_part;         // [slots][2][n_pad] (mean, M2) per (32-row group, utterance)
     const int64_t* offsets;   // device [B+1] row offsets, or nullptr for fixed length
     int n_utts;
     int fixed_T;              // frames per utterance when offsets == nullptr

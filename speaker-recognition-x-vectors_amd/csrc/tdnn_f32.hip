@@ -115,12 +115,13 @@ __device__ __forceinline__ void pool_group(const TdnnArgs& a, const f32x16& v, i
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 struct Ctx {
-    __amdgpu_buffer_rsrc_t xrsrc;   // X + m0*ldx
+    __amdgpu_buffer_rsrc_t xrsrc;   // X + m0*ldx  (tile the load stream is in)
     __amdgpu_buffer_rsrc_t wrsrc;   // W + n0*k_pad
     int x_toff;          // (r0*ldx + c*4) * 4 bytes  (per thread)
     int w_toff;          // (r0*k_pad + c*4) * 4 bytes
-    int64_t m0;          // first flat row of the tile
-    int tap, kc, itl;    // next chunk to fetch: (tap, kc) and its linear index
+    int64_t m0;          // first flat row of the tile the load stream is in
+    int64_t g_s, g_end;  // that tile's first row group; end of this block's row range
+    int tap, kc, itl;    // next chunk to fetch: (tap, kc) and its linear index within the tile
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
@@ -141,14 +142,28 @@ __device__ __forceinline__ float4 buf_load16(__amdgpu_buffer_rsrc_t rsrc, int vo
     return make_float4(f.x, f.y, f.z, f.w);
 }
 
-// step to the next K-chunk; past the last one it stays put, so the (unused) look-ahead loads of
-// the final chunks re-read the last chunk instead of needing their own code path
+// Step the load stream to the next K-chunk.  The stream is continuous over the block's tiles:
+// after the last chunk of a tile it moves to chunk 0 of the next tile (same channel column, next
+// <=4 row groups), so a tile's first chunks are already in flight / in LDS when its MFMAs start
+// and only the first tile of a block pays a prologue.  Past the block's last chunk it stays put
+// (the look-ahead of the final chunks re-reads that chunk; the data is never used).
 __device__ __forceinline__ void advance(const TdnnArgs& a, Ctx& cx, int n_chunks) {
     if (cx.itl + 1 < n_chunks) {
         ++cx.itl;
         if (++cx.kc == a.cpt) {
             cx.kc = 0;
             ++cx.tap;
+        }
+    } else {
+        const int64_t g_rem = cx.g_end - cx.g_s;
+        const int64_t g_next = cx.g_s + (g_rem < 4 ? g_rem : 4);
+        if (g_next < cx.g_end) {
+            cx.g_s = g_next;
+            cx.m0 = g_next * 32;
+            cx.xrsrc = make_rsrc(a.X + cx.m0 * (int64_t)a.ldx);
+            cx.itl = 0;
+            cx.kc = 0;
+            cx.tap = 0;
         }
     }
 }
@@ -162,13 +177,13 @@ __device__ __forceinline__ void advance(const TdnnArgs& a, Ctx& cx, int n_chunks
 #define XV_KO(q_) ((((2 * (q_)) + h) ^ sw) << 2)
 // fragment reads (LDS -> VGPR) of k-group q_ into fragment set f_ from buffer base S_
 #define XV_FRG_A(i_, q_, f_, S_) \
-    if constexpr (G > i_) { fa##i_##_##f_ = *reinterpret_cast<const float4*>((S_) + a_rd + i_ * 32 * kBK + XV_KO(q_)); }
-#define XV_FRG_B(q_, f_, S_) fb_##f_ = *reinterpret_cast<const float4*>((S_) + b_rd + XV_KO(q_));
+    if constexpr (G > i_) { rg.fa##i_##_##f_ = *reinterpret_cast<const float4*>((S_) + a_rd + i_ * 32 * kBK + XV_KO(q_)); }
+#define XV_FRG_B(q_, f_, S_) rg.fb_##f_ = *reinterpret_cast<const float4*>((S_) + b_rd + XV_KO(q_));
 // LDS stores of staging set n_ into LDS buffer n_
 #define XV_LST_A(i_, n_) \
-    if constexpr (G > i_) { *reinterpret_cast<float4*>(smem + n_ * kStageFloats + st_off + i_ * 32 * kBK) = sA##i_##_##n_; }
+    if constexpr (G > i_) { *reinterpret_cast<float4*>(smem + n_ * kStageFloats + st_off + i_ * 32 * kBK) = rg.sA##i_##_##n_; }
 #define XV_LST_B(j_, n_) \
-    *reinterpret_cast<float4*>(smem + n_ * kStageFloats + st_off + kBM * kBK + j_ * 32 * kBK) = sB##j_##_##n_;
+    *reinterpret_cast<float4*>(smem + n_ * kStageFloats + st_off + kBM * kBK + j_ * 32 * kBK) = rg.sB##j_##_##n_;
 // global loads of the chunk cx points at into staging set n_
 #define XV_GLD_A(i_, n_)                                                                                  \
     if constexpr (G > i_) {                                                                               \
@@ -177,14 +192,14 @@ __device__ __forceinline__ void advance(const TdnnArgs& a, Ctx& cx, int n_chunks
         if (GUARD) {                                                                                      \
             const bool ok = (cx.m0 + r0 + 32 * i_ + row_shift < a.x_rows) && (cx.kc * kBK + c * 4 < a.kpt); \
             const float4 t = buf_load16(cx.xrsrc, ok ? cx.x_toff : 0, ok ? soff : 0);                     \
-            sA##i_##_##n_ = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);                                     \
+            rg.sA##i_##_##n_ = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);                                     \
         } else {                                                                                          \
-            sA##i_##_##n_ = buf_load16(cx.xrsrc, cx.x_toff, soff);                                        \
+            rg.sA##i_##_##n_ = buf_load16(cx.xrsrc, cx.x_toff, soff);                                        \
         }                                                                                                 \
     }
 #define XV_GLD_B(j_, n_)                                                                                  \
     {                                                                                                     \
-        sB##j_##_##n_ = buf_load16(cx.wrsrc, cx.w_toff, (32 * j_ * a.k_pad + cx.itl * kBK) * 4);          \
+        rg.sB##j_##_##n_ = buf_load16(cx.wrsrc, cx.w_toff, (32 * j_ * a.k_pad + cx.itl * kBK) * 4);          \
     }
 #define XV_GLD_ALL(n_) XV_GLD_A(0, n_) XV_GLD_A(1, n_) XV_GLD_A(2, n_) XV_GLD_A(3, n_) \
                        XV_GLD_B(0, n_) XV_GLD_B(1, n_) XV_GLD_B(2, n_) XV_GLD_B(3, n_)
@@ -193,7 +208,7 @@ __device__ __forceinline__ void advance(const TdnnArgs& a, Ctx& cx, int n_chunks
 // one MFMA (row group i_, k component c_, fragment set f_) and the statement slotted behind it
 #define XV_MF(i_, c_, f_, slot_)                                                                          \
     if constexpr (G > i_) {                                                                               \
-        acc##i_ = __builtin_amdgcn_mfma_f32_32x32x2f32(fa##i_##_##f_.c_, fb_##f_.c_, acc##i_, 0, 0, 0);   \
+        acc##i_ = __builtin_amdgcn_mfma_f32_32x32x2f32(rg.fa##i_##_##f_.c_, rg.fb_##f_.c_, acc##i_, 0, 0, 0);   \
     }                                                                                                     \
     SB();                                                                                                 \
     slot_                                                                                                 \
@@ -231,40 +246,26 @@ __device__ __forceinline__ void advance(const TdnnArgs& a, Ctx& cx, int n_chunks
               XV_NOP, XV_NOP, XV_NOP, XV_NOP, XV_NOP, XV_NOP, XV_NOP, XV_NOP)                             \
     }
 
-// One tile of G row groups (32 frames each) x 128 channels, starting at row group g0.
-template <int G, bool GUARD, bool POOL, bool STORE>
-__device__ __forceinline__ void process_tile(const TdnnArgs& a, float* smem, int64_t g0, int n0) {
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 31, h = lane >> 5;
-    // staging map: thread -> (row r0 + 32*j, 16-byte chunk c) of a 32-wide K chunk
-    const int c = tid & 7, r0 = tid >> 3;
-    const int st_off = r0 * kBK + ((c ^ ((r0 >> 1) & 7)) << 2);
-    // fragment read map: row (base + r), logical 16-B chunk 2q+h, swizzled by row
-    const int sw = (r >> 1) & 7;
-    const int a_rd = r * kBK;
-    const int b_rd = kBM * kBK + (wave * 32 + r) * kBK;
-    const int n_chunks = a.n_taps * a.cpt;
-
-    Ctx cx;
-    cx.m0 = g0 * 32;
-    cx.xrsrc = make_rsrc(a.X + cx.m0 * (int64_t)a.ldx);
-    cx.wrsrc = make_rsrc(a.W + (int64_t)n0 * a.k_pad);
-    cx.x_toff = (r0 * a.ldx + c * 4) * 4;
-    cx.w_toff = (r0 * a.k_pad + c * 4) * 4;
-    cx.tap = 0;
-    cx.kc = 0;
-    cx.itl = 0;
-
-    // two staging sets (_0/_1): A row groups 0..3 and W row blocks 0..3; two fragment sets
+// Pipeline registers that live across tiles: two staging sets (_0/_1: A row groups 0..3 and W
+// row blocks 0..3 of a chunk in flight) and two fragment sets.  A struct of named members, not
+// arrays (see above).
+struct Regs {
     float4 sA0_0, sA1_0, sA2_0, sA3_0, sB0_0, sB1_0, sB2_0, sB3_0;
     float4 sA0_1, sA1_1, sA2_1, sA3_1, sB0_1, sB1_1, sB2_1, sB3_1;
     float4 fa0_0, fa1_0, fa2_0, fa3_0, fb_0, fa0_1, fa1_1, fa2_1, fa3_1, fb_1;
-    f32x16 acc0, acc1, acc2, acc3;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; acc2[e] = 0.f; acc3[e] = 0.f; }
+};
 
-    // ---- tile prologue: chunk 0 -> LDS buffer 0; chunks 1 and 2 in flight in the two sets
+struct Lane {
+    int h, sw, a_rd, b_rd, st_off, r0, c, col_in_tile;
+};
+
+// Once per block: chunk 0 of the first tile -> LDS buffer 0, its first fragments -> set 0,
+// chunks 1 and 2 in flight in the two staging sets.
+template <bool GUARD>
+__device__ __forceinline__ void block_prologue(const TdnnArgs& a, float* smem, Ctx& cx, Regs& rg, const Lane& ln,
+                                               int n_chunks) {
+    constexpr int G = 4;   // fetch all four row groups: rows past a short first tile are allocated
+    const int h = ln.h, sw = ln.sw, a_rd = ln.a_rd, b_rd = ln.b_rd, st_off = ln.st_off, r0 = ln.r0, c = ln.c;
     XV_GLD_ALL(0)
     advance(a, cx, n_chunks);
     XV_GLD_ALL(1)
@@ -277,16 +278,28 @@ __device__ __forceinline__ void process_tile(const TdnnArgs& a, float* smem, int
     XV_FRG_A(0, 0, 0, smem) XV_FRG_A(1, 0, 0, smem) XV_FRG_A(2, 0, 0, smem) XV_FRG_A(3, 0, 0, smem)
     XV_FRG_B(0, 0, smem)
     SB();
+}
 
-    // ---- main loop over K chunks, two per trip (LDS buffer 0 then 1); n_chunks is even
+// One tile of G row groups (32 frames each) x 128 channels, starting at row group g0.  On entry
+// the pipeline is primed for this tile (block_prologue or the previous tile's last chunks).
+template <int G, bool GUARD, bool POOL, bool STORE>
+__device__ __forceinline__ void process_tile(const TdnnArgs& a, float* smem, Ctx& cx, Regs& rg, const Lane& ln,
+                                             int64_t g0, int n0, int n_chunks) {
+    const int h = ln.h, sw = ln.sw, a_rd = ln.a_rd, b_rd = ln.b_rd, st_off = ln.st_off, r0 = ln.r0, c = ln.c;
+    f32x16 acc0, acc1, acc2, acc3;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; acc2[e] = 0.f; acc3[e] = 0.f; }
+
+    // ---- K chunks, two per trip (LDS buffer 0 then 1); n_chunks is even
     for (int it = 0; it < n_chunks; it += 2) {
         XV_CHUNK(0, 1)
         XV_CHUNK(1, 0)
     }
 
+    const int64_t m0 = g0 * 32;
     // ---- epilogue: bias + ReLU + folded BatchNorm (tdnn_layer.py:30-39)
     // accumulator element e of lane (r, h): row = (e&3) + 8*(e>>2) + 4*h, col = r
-    const int col = n0 + wave * 32 + r;
+    const int col = n0 + ln.col_in_tile;
     const float bi = a.bias[col], sc = a.scale[col], sh = a.shift[col];
 #define XV_EPI(i_)                                                                                        \
     if constexpr (G > i_) {                                                                               \
@@ -296,16 +309,14 @@ __device__ __forceinline__ void process_tile(const TdnnArgs& a, float* smem, int
             v = fmaf(v, sc, sh);                                                                          \
             acc##i_[e] = v;                                                                               \
             if (STORE) {                                                                                  \
-                const int64_t row = cx.m0 + i_ * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;                     \
+                const int64_t row = m0 + i_ * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;                     \
                 a.Y[row * a.ldy + col] = v;                                                               \
             }                                                                                             \
         }                                                                                                 \
-        if (POOL) pool_group(a, acc##i_, cx.m0 + i_ * 32, h, col);                                        \
+        if (POOL) pool_group(a, acc##i_, m0 + i_ * 32, h, col);                                        \
     }
     XV_EPI(0) XV_EPI(1) XV_EPI(2) XV_EPI(3)
 #undef XV_EPI
-    // the next tile's prologue overwrites LDS buffer 0: every wave must be done reading
-    __syncthreads();
 }
 
 template <bool GUARD, bool POOL, bool STORE>
@@ -322,12 +333,43 @@ __global__ __launch_bounds__(256, 2) void tdnn_f32_kernel(const TdnnArgs a) {
     const int64_t g_begin = a.groups_total * (int64_t)p / a.blocks_per_col;
     const int64_t g_end = a.groups_total * (int64_t)(p + 1) / a.blocks_per_col;
     const int n0 = j * kBN;
+    const int n_chunks = a.n_taps * a.cpt;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    Lane ln;
+    ln.h = lane >> 5;
+    const int r = lane & 31;
+    // staging map: thread -> (row r0 + 32*j, 16-byte chunk c) of a 32-wide K chunk
+    ln.c = tid & 7;
+    ln.r0 = tid >> 3;
+    ln.st_off = ln.r0 * kBK + ((ln.c ^ ((ln.r0 >> 1) & 7)) << 2);
+    // fragment read map: row (base + r), logical 16-B chunk 2q+h, swizzled by row
+    ln.sw = (r >> 1) & 7;
+    ln.a_rd = r * kBK;
+    ln.b_rd = kBM * kBK + (wave * 32 + r) * kBK;
+    ln.col_in_tile = wave * 32 + r;
+
+    Ctx cx;
+    cx.g_s = g_begin;
+    cx.g_end = g_end;
+    cx.m0 = g_begin * 32;
+    cx.xrsrc = make_rsrc(a.X + cx.m0 * (int64_t)a.ldx);
+    cx.wrsrc = make_rsrc(a.W + (int64_t)n0 * a.k_pad);
+    cx.x_toff = (ln.r0 * a.ldx + ln.c * 4) * 4;
+    cx.w_toff = (ln.r0 * a.k_pad + ln.c * 4) * 4;
+    cx.tap = 0;
+    cx.kc = 0;
+    cx.itl = 0;
+
+    Regs rg;
+    block_prologue<GUARD>(a, smem, cx, rg, ln, n_chunks);
     int64_t g = g_begin;
-    for (; g + 4 <= g_end; g += 4) process_tile<4, GUARD, POOL, STORE>(a, smem, g, n0);
+    for (; g + 4 <= g_end; g += 4) process_tile<4, GUARD, POOL, STORE>(a, smem, cx, rg, ln, g, n0, n_chunks);
     const int rem = (int)(g_end - g);
-    if (rem == 3) process_tile<3, GUARD, POOL, STORE>(a, smem, g, n0);
-    else if (rem == 2) process_tile<2, GUARD, POOL, STORE>(a, smem, g, n0);
-    else if (rem == 1) process_tile<1, GUARD, POOL, STORE>(a, smem, g, n0);
+    if (rem == 3) process_tile<3, GUARD, POOL, STORE>(a, smem, cx, rg, ln, g, n0, n_chunks);
+    else if (rem == 2) process_tile<2, GUARD, POOL, STORE>(a, smem, cx, rg, ln, g, n0, n_chunks);
+    else if (rem == 1) process_tile<1, GUARD, POOL, STORE>(a, smem, cx, rg, ln, g, n0, n_chunks);
 #ifdef XVEC_DIAG
     if (threadIdx.x == 0 && blockIdx.x < 8192) {
         __builtin_amdgcn_s_waitcnt(0);

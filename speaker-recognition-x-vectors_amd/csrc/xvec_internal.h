@@ -7,7 +7,7 @@
 namespace xvec {
 
 constexpr int kBK = 32;          // K-chunk (fp32 elements) staged per main-loop step
-constexpr int kRowPadTail = 8;   // readable garbage rows past M_pad (max tap reach is 6)
+constexpr int kRowPadTail = 136; // readable rows past M_pad: a 4-group look-ahead fetch (128) + max tap reach (6)
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 inline int64_t round_up64(int64_t v, int64_t m) { return (v + m - 1) / m * m; }

@@ -32,6 +32,19 @@ def layer_flops(T):
             2 * 512 * 512 * (T - 14), 2 * 512 * 1500 * (T - 14) + 4 * 1500 * (T - 14)]
 
 
+def usable_cpus():
+    """CPU share of this process: the smaller of the affinity mask and the cgroup quota
+    (the GPU box shows 256 logical CPUs but grants a 16-CPU quota per GPU)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def total_flops(T):
     return sum(layer_flops(T)) + 2 * 3000 * 512
 
@@ -97,6 +110,17 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # ---- boundary hands over host buffers: same steps with a pinned H2D of x and a D2H of the
+    # embeddings per step, not overlapped (reported beside the headline, never as `value`)
+    x_host = x.cpu().pin_memory()
+    out_host = torch.empty((B, 512), dtype=torch.float32).pin_memory()
+    torch.cuda.synchronize(dev)
+    t1 = time.perf_counter()
+    for k in range(K):
+        out_host.copy_(model.extract_x_vec(x_host.to(dev, non_blocking=True)), non_blocking=True)
+    torch.cuda.synchronize(dev)
+    dt_pcie = time.perf_counter() - t1
+
     # ---- per-kernel durations: hipEvents recorded by the library on the launch stream -----
     model.set_profiling(True, dev)
     names = ("tdnn1", "tdnn2", "tdnn3", "tdnn4", "tdnn5_pool", "pool_finalize", "segment6")
@@ -118,18 +142,29 @@ def main():
         dom_flops = (lf[1] + lf[2] + lf[3]) / 3
         achieved = dom_flops / (dom_ms * 1e-3) / 1e12
         value = world * K * B / dt
+        # HBM bytes per launch of the dominant kernel come from the committed rocprofv3 --pmc pass of
+        # this same command (profiles/traffic.json, written by profiles/summarize_pmc.py); counters
+        # cannot be collected from inside the benchmark process.
+        traffic, traffic_src = None, None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+            traffic, traffic_src = tj["tdnn_f32_kernel<false, false, true>"]["hbm_bytes_per_launch"], tj["source"]
+        except (OSError, KeyError, ValueError):
+            pass
         out = {
             "metric": "x-vector embeddings/sec (300-frame utt)", "value": round(value, 1), "unit": "embeddings/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(dt / K * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"configs[1]: 1xMI355X batch={B} fixed {T}-frame x 24-MFCC utterances, fp32, "
                                    "extract_x_vec layer 6, random-init weights seed 42",
-                       "batch_per_gpu": B, "frames": T, "sharding": f"utterance-sharded x{world}"
+                       "batch_per_gpu": B, "frames": T,
+                       "pcie_inclusive_embeddings_per_s_per_gpu": round(K * B / dt_pcie, 1),
+                       "sharding": f"utterance-sharded x{world}"
                        + (", one all-gather of [K*B,512] fp32 in the timed region" if world > 1 else "")},
             "roofline": {
-                "bound": "mfma", "kernel": "tdnn_f32_kernel<128,128,false,false,true> (layers 2-4)",
+                "bound": "mfma", "kernel": "xvec::tdnn_f32_kernel<false,false,true> (layers 2-4)",
                 "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK / 1e12, "unit": "TFLOP/s",
-                "frac": round(achieved * 1e12 / FP32_MFMA_PEAK, 4), "traffic": None,
+                "frac": round(achieved * 1e12 / FP32_MFMA_PEAK, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "avg_launch_ms": round(dom_ms, 4), "flops_per_launch": dom_flops,
                 "per_kernel_ms": {n: round(v, 4) for n, v in avg_ms.items()},
                 "per_kernel_tflops": {n: round(lf[i] / (avg_ms[n] * 1e-3) / 1e12, 2) for i, n in enumerate(tdnn_names)},
@@ -143,7 +178,7 @@ def main():
             import xvector_oracle as oracle
             p = {k: v for k, v in sd.items() if v.is_floating_point()}
             eps, threads, n_utts, secs = oracle.time_cpu_baseline(p, T=T, batch=64, budget_s=args.cpu_budget,
-                                                                  threads=os.cpu_count())
+                                                                  threads=usable_cpus())
             out["cpu_baseline"] = {"value": round(eps, 1), "unit": "embeddings/s", "cores": threads, "kind": "port",
                                    "sample": f"{n_utts} utterances of {T} frames in batches of 64, fp32, "
                                              f"{secs:.1f} s of oracle/xvector_oracle.py (PyTorch CPU restatement of "

@@ -147,6 +147,42 @@ class XVectorModel(nn.Module):
         self._engines = {}
         self.eval()   # extraction-only build: BatchNorm always uses running statistics
 
+    # ------------------------------------------------------------------ checkpoint ingestion (N2)
+    _CTOR_KEYS = ("input_size", "hidden_size", "num_classes", "x_vector_size", "x_vec_extract_layer",
+                  "batch_size", "learning_rate", "batch_norm", "dropout_p", "augmentations_per_sample",
+                  "data_folder_path")
+
+    @classmethod
+    def load_from_checkpoint(cls, checkpoint_path, map_location="cpu", **overrides):
+        """Counterpart of Lightning's `XVectorModel.load_from_checkpoint(path)` (reference
+        main.py:213) without Lightning installed: reads `ckpt['hyper_parameters']` (what
+        `save_hyperparameters()` stored, main.py:56) and `ckpt['state_dict']` from a reference
+        `.ckpt` file.  Classes the pickle refers to but that are not importable here (Lightning's
+        AttributeDict, callbacks) are read as plain dicts."""
+        import pickle
+
+        class _Lenient(pickle.Unpickler):
+            def find_class(self, module, name):
+                try:
+                    return super().find_class(module, name)
+                except (ImportError, AttributeError):
+                    return type(name, (dict,), {"__setstate__": lambda self, st: self.update(st or {})})
+
+        class _PickleModule:
+            Unpickler = _Lenient
+            load = staticmethod(lambda f, **kw: _Lenient(f, **kw).load())
+            __name__ = "lenient_pickle"
+
+        ckpt = torch.load(checkpoint_path, map_location=map_location, weights_only=False,
+                          pickle_module=_PickleModule)
+        hp = dict(ckpt.get("hyper_parameters", {}))
+        hp.update(overrides)
+        model = cls(**{k: hp[k] for k in cls._CTOR_KEYS if k in hp})
+        sd = {k: v for k, v in ckpt["state_dict"].items()
+              if k.startswith(("time_context_layers.", "segment_layer6.", "segment_layer7.", "output."))}
+        model.load_state_dict(sd)
+        return model
+
     # ------------------------------------------------------------------ engine plumbing
     def _check_mode(self):
         if self.training:

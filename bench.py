@@ -23,6 +23,7 @@ import torch
 
 HBM_PEAK = 8.0e12         # B/s, MI355X_MICROARCH.md (spec)
 FP32_MFMA_PEAK = 157.3e12  # FLOP/s dense fp32 MFMA (= fp32 vector peak), MI355X_MICROARCH.md
+BF16_MFMA_PEAK = 2.5e15    # FLOP/s dense bf16 MFMA, MI355X_MICROARCH.md
 BYTES_PER_UTT = 8_238_208  # every layer reads its input once, writes its output once (T=300, fp32)
 
 
@@ -57,6 +58,8 @@ def main():
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--frames", type=int, default=300)
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU-baseline work (0 = skip)")
+    ap.add_argument("--dtype", choices=("fp32", "bf16"), default="fp32",
+                    help="frame-level arithmetic; the headline (BASELINE configs[1]) is fp32")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -77,7 +80,7 @@ def main():
 
     B, T, K, W = args.batch, args.frames, args.steps, args.warmup
     sd = {k: torch.from_numpy(np.asarray(v)) for k, v in xa.synth.make_state_dict(seed=42).items()}
-    model = xa.XVectorModel()
+    model = xa.XVectorModel(precision=args.dtype)
     model.load_state_dict(sd)
     model = model.to(dev).eval()
     gen = torch.Generator(device=dev).manual_seed(1000 + rank)
@@ -141,6 +144,10 @@ def main():
         dom_ms = (avg_ms["tdnn2"] + avg_ms["tdnn3"] + avg_ms["tdnn4"]) / 3
         dom_flops = (lf[1] + lf[2] + lf[3]) / 3
         achieved = dom_flops / (dom_ms * 1e-3) / 1e12
+        bf = args.dtype == "bf16"
+        peak = BF16_MFMA_PEAK if bf else FP32_MFMA_PEAK
+        dom_kernel = ("xvec::tdnn_kernel<false,false,true,true,true> (layers 2-4, bf16 MFMA)" if bf else
+                      "xvec::tdnn_kernel<false,false,true,false,false> (layers 2-4, fp32 MFMA)")
         value = world * K * B / dt
         # HBM bytes per launch of the dominant kernel come from the committed rocprofv3 --pmc pass of
         # this same command (profiles/traffic.json, written by profiles/summarize_pmc.py); counters
@@ -148,28 +155,31 @@ def main():
         traffic, traffic_src = None, None
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-            traffic, traffic_src = tj["tdnn_f32_kernel<false, false, true>"]["hbm_bytes_per_launch"], tj["source"]
+            key = "tdnn_kernel<false, false, true, true, true>" if args.dtype == "bf16" else \
+                "tdnn_kernel<false, false, true, false, false>"
+            traffic, traffic_src = tj[key]["hbm_bytes_per_launch"], tj["source"]
         except (OSError, KeyError, ValueError):
             pass
         out = {
             "metric": "x-vector embeddings/sec (300-frame utt)", "value": round(value, 1), "unit": "embeddings/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(dt / K * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"configs[1]: 1xMI355X batch={B} fixed {T}-frame x 24-MFCC utterances, fp32, "
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.dtype == "fp32" else "bf16", "data": "synthetic",
+            "config": {"workload": f"configs[{1 if args.dtype == 'fp32' else 4}]: 1xMI355X batch={B} fixed {T}-frame x 24-MFCC "
+                                   f"utterances, {args.dtype} frame-level stack, "
                                    "extract_x_vec layer 6, random-init weights seed 42",
                        "batch_per_gpu": B, "frames": T,
                        "pcie_inclusive_embeddings_per_s_per_gpu": round(K * B / dt_pcie, 1),
                        "sharding": f"utterance-sharded x{world}"
                        + (", one all-gather of [K*B,512] fp32 in the timed region" if world > 1 else "")},
             "roofline": {
-                "bound": "mfma", "kernel": "xvec::tdnn_f32_kernel<false,false,true> (layers 2-4)",
-                "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK / 1e12, "unit": "TFLOP/s",
-                "frac": round(achieved * 1e12 / FP32_MFMA_PEAK, 4), "traffic": traffic, "traffic_source": traffic_src,
+                "bound": "mfma", "kernel": dom_kernel,
+                "achieved": round(achieved, 2), "peak": peak / 1e12, "unit": "TFLOP/s",
+                "frac": round(achieved * 1e12 / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "avg_launch_ms": round(dom_ms, 4), "flops_per_launch": dom_flops,
                 "per_kernel_ms": {n: round(v, 4) for n, v in avg_ms.items()},
                 "per_kernel_tflops": {n: round(lf[i] / (avg_ms[n] * 1e-3) / 1e12, 2) for i, n in enumerate(tdnn_names)},
                 "tdnn_stack_tflops": round(sum(lf) / (tdnn_ms * 1e-3) / 1e12, 2),
-                "path_flop_frac_of_fp32_peak": round(value / world * total_flops(T) / FP32_MFMA_PEAK, 4),
+                "path_flop_frac_of_peak": round(value / world * total_flops(T) / peak, 4),
                 "path_hbm_frac_algorithmic": round(value / world * BYTES_PER_UTT / HBM_PEAK, 4),
             },
         }

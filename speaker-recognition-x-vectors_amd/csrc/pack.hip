@@ -6,7 +6,8 @@ namespace xvec {
 
 // PyTorch TdnnLayer.linear.weight[out, taps*cin] (column = tap*cin + c, tdnn_layer.py:19,29)
 //   -> Wp[n_pad][k_pad], k = tap*tap_stride + c, zero padded.
-__global__ void pack_tdnn_weight_kernel(const float* __restrict__ W, TdnnGeom g, float* __restrict__ Wp) {
+template <typename TO>
+__global__ void pack_tdnn_weight_kernel(const float* __restrict__ W, TdnnGeom g, TO* __restrict__ Wp) {
     const int64_t total = (int64_t)g.n_pad * g.k_pad;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
          i += (int64_t)gridDim.x * blockDim.x) {
@@ -15,7 +16,7 @@ __global__ void pack_tdnn_weight_kernel(const float* __restrict__ W, TdnnGeom g,
         float v = 0.f;
         if (n < g.cout && tap < g.src_taps && c < g.src_cin)
             v = W[(int64_t)n * (g.src_taps * g.src_cin) + tap * g.src_cin + c];
-        Wp[i] = v;
+        Wp[i] = (TO)v;
     }
 }
 
@@ -47,61 +48,74 @@ __global__ void pack_tdnn_vec_kernel(const float* __restrict__ bias, const float
 hipError_t launch_pack_tdnn(const float* W, const float* bias, const float* g, const float* be,
                             const float* mu, const float* var, float eps, const TdnnGeom& geo,
                             float* Wp, float* bias_p, float* scale_p, float* shift_p, hipStream_t s) {
-    pack_tdnn_weight_kernel<<<1024, 256, 0, s>>>(W, geo, Wp);
+    pack_tdnn_weight_kernel<float><<<1024, 256, 0, s>>>(W, geo, Wp);
     pack_tdnn_vec_kernel<<<(geo.n_pad + 255) / 256, 256, 0, s>>>(bias, g, be, mu, var, eps, geo.cout,
                                                                  geo.n_pad, bias_p, scale_p, shift_p);
     return hipGetLastError();
 }
 
+hipError_t launch_pack_tdnn_bf16(const float* W, const TdnnGeom& geo, void* Wp16, hipStream_t s) {
+    pack_tdnn_weight_kernel<__bf16><<<1024, 256, 0, s>>>(W, geo, static_cast<__bf16*>(Wp16));
+    return hipGetLastError();
+}
+
 // x[B,T,C] -> packed rows out[offsets[u] + t][c_pad] for t < len_u (zero padded channels).
+template <typename TO>
 __global__ void pack_rows_kernel(const float* __restrict__ x, const int64_t* __restrict__ offsets, int T,
-                                 int C, int c_pad, float* __restrict__ out) {
+                                 int C, int c_pad, TO* __restrict__ out) {
     const int u = blockIdx.y;
     const int64_t off = offsets ? offsets[u] : (int64_t)u * T;
     const int64_t len = offsets ? offsets[u + 1] - off : T;
     const int64_t total = len * c_pad;
     const float* src = x + (int64_t)u * T * C;
-    float* dst = out + off * c_pad;
+    TO* dst = out + off * c_pad;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
          i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t t = i / c_pad;
         const int c = (int)(i % c_pad);
-        dst[i] = (c < C) ? src[t * C + c] : 0.f;
+        dst[i] = (TO)((c < C) ? src[t * C + c] : 0.f);
     }
 }
 
 hipError_t launch_pack_rows(const float* x, const int64_t* offsets, int B, int T, int C, int c_pad,
-                            float* out, hipStream_t s) {
+                            void* out, bool out_bf16, hipStream_t s) {
     if (B <= 0) return hipSuccess;
     const int64_t per = (int64_t)T * c_pad;
     int gx = (int)((per + 255) / 256);
     if (gx > 64) gx = 64;
-    pack_rows_kernel<<<dim3(gx, B), 256, 0, s>>>(x, offsets, T, C, c_pad, out);
+    if (out_bf16)
+        pack_rows_kernel<__bf16><<<dim3(gx, B), 256, 0, s>>>(x, offsets, T, C, c_pad, static_cast<__bf16*>(out));
+    else
+        pack_rows_kernel<float><<<dim3(gx, B), 256, 0, s>>>(x, offsets, T, C, c_pad, static_cast<float*>(out));
     return hipGetLastError();
 }
 
 // flat[u*T_in + t][ld] -> y[u][t][0..C) for t < T_out
-__global__ void unpack_rows_kernel(const float* __restrict__ flat, int ld, int T_in, int T_out, int C,
+template <typename TI>
+__global__ void unpack_rows_kernel(const TI* __restrict__ flat, int ld, int T_in, int T_out, int C,
                                    float* __restrict__ y) {
     const int u = blockIdx.y;
     const int64_t total = (int64_t)T_out * C;
-    const float* src = flat + (int64_t)u * T_in * ld;
+    const TI* src = flat + (int64_t)u * T_in * ld;
     float* dst = y + (int64_t)u * total;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
          i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t t = i / C;
         const int c = (int)(i % C);
-        dst[i] = src[t * ld + c];
+        dst[i] = (float)src[t * ld + c];
     }
 }
 
-hipError_t launch_unpack_rows(const float* flat, int ld, int B, int T_in, int T_out, int C, float* y,
+hipError_t launch_unpack_rows(const void* flat, bool in_bf16, int ld, int B, int T_in, int T_out, int C, float* y,
                               hipStream_t s) {
     if (B <= 0 || T_out <= 0) return hipSuccess;
     const int64_t per = (int64_t)T_out * C;
     int gx = (int)((per + 255) / 256);
     if (gx > 64) gx = 64;
-    unpack_rows_kernel<<<dim3(gx, B), 256, 0, s>>>(flat, ld, T_in, T_out, C, y);
+    if (in_bf16)
+        unpack_rows_kernel<__bf16><<<dim3(gx, B), 256, 0, s>>>(static_cast<const __bf16*>(flat), ld, T_in, T_out, C, y);
+    else
+        unpack_rows_kernel<float><<<dim3(gx, B), 256, 0, s>>>(static_cast<const float*>(flat), ld, T_in, T_out, C, y);
     return hipGetLastError();
 }
 

@@ -1,4 +1,5 @@
-// Frame-level TDNN layer for gfx950 (MI355X), exact fp32:
+// Frame-level TDNN layer for gfx950 (MI355X): exact fp32 (v_mfma_f32_32x32x2_f32) or bf16 inputs with
+// fp32 accumulation (v_mfma_f32_32x32x16_bf16):
 //   Y[p, n] = relu( sum_{tap, c} X[p + tap*dil, c] * W[n, tap, c] + bias[n] ) * scale[n] + shift[n]
 // i.e. tdnn_layer.py:26-41 of the reference (context concat -> Linear -> ReLU -> eval
 // BatchNorm1d) as ONE implicit-GEMM kernel over the flat frame axis.  No context copy
@@ -114,6 +115,7 @@ __device__ __forceinline__ void pool_group(const TdnnArgs& a, const f32x16& v, i
 // per-load 64-bit address is ever computed or kept in VGPRs.
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 struct Ctx {
     __amdgpu_buffer_rsrc_t xrsrc;   // X + m0*ldx  (tile the load stream is in)
     __amdgpu_buffer_rsrc_t wrsrc;   // W + n0*k_pad
@@ -122,6 +124,7 @@ struct Ctx {
     int64_t m0;          // first flat row of the tile the load stream is in
     int64_t g_s, g_end;  // that tile's first row group; end of this block's row range
     int tap, kc, itl;    // next chunk to fetch: (tap, kc) and its linear index within the tile
+    int es;              // bytes per input element (4: fp32, 2: bf16)
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
@@ -160,7 +163,7 @@ __device__ __forceinline__ void advance(const TdnnArgs& a, Ctx& cx, int n_chunks
         if (g_next < cx.g_end) {
             cx.g_s = g_next;
             cx.m0 = g_next * 32;
-            cx.xrsrc = make_rsrc(a.X + cx.m0 * (int64_t)a.ldx);
+            cx.xrsrc = make_rsrc(static_cast<const char*>(a.X) + cx.m0 * (int64_t)a.ldx * cx.es);
             cx.itl = 0;
             cx.kc = 0;
             cx.tap = 0;
@@ -188,9 +191,9 @@ __device__ __forceinline__ void advance(const TdnnArgs& a, Ctx& cx, int n_chunks
 #define XV_GLD_A(i_, n_)                                                                                  \
     if constexpr (G > i_) {                                                                               \
         const int row_shift = cx.tap * a.tap_rows;                                                        \
-        const int soff = ((row_shift + 32 * i_) * a.ldx + cx.kc * kBK) * 4;                               \
+        const int soff = ((row_shift + 32 * i_) * a.ldx + cx.kc * BKE) * ES;                              \
         if (GUARD) {                                                                                      \
-            const bool ok = (cx.m0 + r0 + 32 * i_ + row_shift < a.x_rows) && (cx.kc * kBK + c * 4 < a.kpt); \
+            const bool ok = (cx.m0 + r0 + 32 * i_ + row_shift < a.x_rows) && (cx.kc * BKE + c * (16 / ES) < a.kpt); \
             const float4 t = buf_load16(cx.xrsrc, ok ? cx.x_toff : 0, ok ? soff : 0);                     \
             rg.sA##i_##_##n_ = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);                                     \
         } else {                                                                                          \
@@ -199,13 +202,13 @@ __device__ __forceinline__ void advance(const TdnnArgs& a, Ctx& cx, int n_chunks
     }
 #define XV_GLD_B(j_, n_)                                                                                  \
     {                                                                                                     \
-        rg.sB##j_##_##n_ = buf_load16(cx.wrsrc, cx.w_toff, (32 * j_ * a.k_pad + cx.itl * kBK) * 4);          \
+        rg.sB##j_##_##n_ = buf_load16(cx.wrsrc, cx.w_toff, (32 * j_ * a.k_pad + cx.itl * BKE) * ES);         \
     }
 #define XV_GLD_ALL(n_) XV_GLD_A(0, n_) XV_GLD_A(1, n_) XV_GLD_A(2, n_) XV_GLD_A(3, n_) \
                        XV_GLD_B(0, n_) XV_GLD_B(1, n_) XV_GLD_B(2, n_) XV_GLD_B(3, n_)
 #define XV_LST_ALL(n_) XV_LST_A(0, n_) XV_LST_A(1, n_) XV_LST_A(2, n_) XV_LST_A(3, n_) \
                        XV_LST_B(0, n_) XV_LST_B(1, n_) XV_LST_B(2, n_) XV_LST_B(3, n_)
-// one MFMA (row group i_, k component c_, fragment set f_) and the statement slotted behind it
+// fp32: one MFMA (row group i_, k component c_, fragment set f_) and the statement slotted behind it
 #define XV_MF(i_, c_, f_, slot_)                                                                          \
     if constexpr (G > i_) {                                                                               \
         acc##i_ = __builtin_amdgcn_mfma_f32_32x32x2f32(rg.fa##i_##_##f_.c_, rg.fb_##f_.c_, acc##i_, 0, 0, 0);   \
@@ -213,12 +216,25 @@ __device__ __forceinline__ void advance(const TdnnArgs& a, Ctx& cx, int n_chunks
     SB();                                                                                                 \
     slot_                                                                                                 \
     SB();
-// one k-group: 4 components x 4 row groups, 16 slots
+// bf16: one MFMA per row group consumes the whole 16-byte fragment (k-step of 16)
+#define XV_MFB(i_, f_)                                                                                    \
+    if constexpr (G > i_) {                                                                               \
+        acc##i_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, rg.fa##i_##_##f_),   \
+                                                          __builtin_bit_cast(bf16x8, rg.fb_##f_), acc##i_, 0, 0, 0); \
+    }                                                                                                     \
+    SB();
+// one k-group with 16 slots.  fp32: 4 k components x 4 row groups = 16 MFMAs, one slot behind each;
+// bf16: 4 MFMAs (k-step 16), four slots behind each
 #define XV_KG(f_, s0, s1, s2, s3, s4, s5, s6, s7, s8, s9, s10, s11, s12, s13, s14, s15)                   \
-    XV_MF(0, x, f_, s0) XV_MF(1, x, f_, s1) XV_MF(2, x, f_, s2) XV_MF(3, x, f_, s3)                       \
-    XV_MF(0, y, f_, s4) XV_MF(1, y, f_, s5) XV_MF(2, y, f_, s6) XV_MF(3, y, f_, s7)                       \
-    XV_MF(0, z, f_, s8) XV_MF(1, z, f_, s9) XV_MF(2, z, f_, s10) XV_MF(3, z, f_, s11)                     \
-    XV_MF(0, w, f_, s12) XV_MF(1, w, f_, s13) XV_MF(2, w, f_, s14) XV_MF(3, w, f_, s15)
+    if constexpr (INBF) {                                                                                 \
+        XV_MFB(0, f_) s0 s1 s2 s3 SB(); XV_MFB(1, f_) s4 s5 s6 s7 SB();                                   \
+        XV_MFB(2, f_) s8 s9 s10 s11 SB(); XV_MFB(3, f_) s12 s13 s14 s15 SB();                             \
+    } else {                                                                                              \
+        XV_MF(0, x, f_, s0) XV_MF(1, x, f_, s1) XV_MF(2, x, f_, s2) XV_MF(3, x, f_, s3)                   \
+        XV_MF(0, y, f_, s4) XV_MF(1, y, f_, s5) XV_MF(2, y, f_, s6) XV_MF(3, y, f_, s7)                   \
+        XV_MF(0, z, f_, s8) XV_MF(1, z, f_, s9) XV_MF(2, z, f_, s10) XV_MF(3, z, f_, s11)                 \
+        XV_MF(0, w, f_, s12) XV_MF(1, w, f_, s13) XV_MF(2, w, f_, s14) XV_MF(3, w, f_, s15)               \
+    }
 #define XV_NOP ;
 // One K-chunk held in LDS buffer P_; N_ = the other buffer = the staging set holding chunk it+1.
 // Branch-free: the last chunk of a tile also stores/loads/reads ahead (clamped to the last
@@ -261,10 +277,11 @@ struct Lane {
 
 // Once per block: chunk 0 of the first tile -> LDS buffer 0, its first fragments -> set 0,
 // chunks 1 and 2 in flight in the two staging sets.
-template <bool GUARD>
+template <bool GUARD, bool INBF>
 __device__ __forceinline__ void block_prologue(const TdnnArgs& a, float* smem, Ctx& cx, Regs& rg, const Lane& ln,
                                                int n_chunks) {
     constexpr int G = 4;   // fetch all four row groups: rows past a short first tile are allocated
+    constexpr int ES = INBF ? 2 : 4, BKE = 128 / ES;
     const int h = ln.h, sw = ln.sw, a_rd = ln.a_rd, b_rd = ln.b_rd, st_off = ln.st_off, r0 = ln.r0, c = ln.c;
     XV_GLD_ALL(0)
     advance(a, cx, n_chunks);
@@ -282,9 +299,10 @@ __device__ __forceinline__ void block_prologue(const TdnnArgs& a, float* smem, C
 
 // One tile of G row groups (32 frames each) x 128 channels, starting at row group g0.  On entry
 // the pipeline is primed for this tile (block_prologue or the previous tile's last chunks).
-template <int G, bool GUARD, bool POOL, bool STORE>
+template <int G, bool GUARD, bool POOL, bool STORE, bool INBF, bool OUTBF>
 __device__ __forceinline__ void process_tile(const TdnnArgs& a, float* smem, Ctx& cx, Regs& rg, const Lane& ln,
                                              int64_t g0, int n0, int n_chunks) {
+    constexpr int ES = INBF ? 2 : 4, BKE = 128 / ES;
     const int h = ln.h, sw = ln.sw, a_rd = ln.a_rd, b_rd = ln.b_rd, st_off = ln.st_off, r0 = ln.r0, c = ln.c;
     f32x16 acc0, acc1, acc2, acc3;
 #pragma unroll
@@ -309,8 +327,9 @@ __device__ __forceinline__ void process_tile(const TdnnArgs& a, float* smem, Ctx
             v = fmaf(v, sc, sh);                                                                          \
             acc##i_[e] = v;                                                                               \
             if (STORE) {                                                                                  \
-                const int64_t row = m0 + i_ * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;                     \
-                a.Y[row * a.ldy + col] = v;                                                               \
+                const int64_t row = m0 + i_ * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;                        \
+                if constexpr (OUTBF) static_cast<__bf16*>(a.Y)[row * a.ldy + col] = (__bf16)v;            \
+                else static_cast<float*>(a.Y)[row * a.ldy + col] = v;                                     \
             }                                                                                             \
         }                                                                                                 \
         if (POOL) pool_group(a, acc##i_, m0 + i_ * 32, h, col);                                        \
@@ -319,8 +338,8 @@ __device__ __forceinline__ void process_tile(const TdnnArgs& a, float* smem, Ctx
 #undef XV_EPI
 }
 
-template <bool GUARD, bool POOL, bool STORE>
-__global__ __launch_bounds__(256, 2) void tdnn_f32_kernel(const TdnnArgs a) {
+template <bool GUARD, bool POOL, bool STORE, bool INBF, bool OUTBF>
+__global__ __launch_bounds__(256, 2) void tdnn_kernel(const TdnnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
 #ifdef XVEC_DIAG
     const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
@@ -354,22 +373,24 @@ __global__ __launch_bounds__(256, 2) void tdnn_f32_kernel(const TdnnArgs a) {
     cx.g_s = g_begin;
     cx.g_end = g_end;
     cx.m0 = g_begin * 32;
-    cx.xrsrc = make_rsrc(a.X + cx.m0 * (int64_t)a.ldx);
-    cx.wrsrc = make_rsrc(a.W + (int64_t)n0 * a.k_pad);
-    cx.x_toff = (ln.r0 * a.ldx + ln.c * 4) * 4;
-    cx.w_toff = (ln.r0 * a.k_pad + ln.c * 4) * 4;
+    constexpr int ES = INBF ? 2 : 4;
+    cx.es = ES;
+    cx.xrsrc = make_rsrc(static_cast<const char*>(a.X) + cx.m0 * (int64_t)a.ldx * ES);
+    cx.wrsrc = make_rsrc(static_cast<const char*>(a.W) + (int64_t)n0 * a.k_pad * ES);
+    cx.x_toff = ln.r0 * a.ldx * ES + ln.c * 16;
+    cx.w_toff = ln.r0 * a.k_pad * ES + ln.c * 16;
     cx.tap = 0;
     cx.kc = 0;
     cx.itl = 0;
 
     Regs rg;
-    block_prologue<GUARD>(a, smem, cx, rg, ln, n_chunks);
+    block_prologue<GUARD, INBF>(a, smem, cx, rg, ln, n_chunks);
     int64_t g = g_begin;
-    for (; g + 4 <= g_end; g += 4) process_tile<4, GUARD, POOL, STORE>(a, smem, cx, rg, ln, g, n0, n_chunks);
+    for (; g + 4 <= g_end; g += 4) process_tile<4, GUARD, POOL, STORE, INBF, OUTBF>(a, smem, cx, rg, ln, g, n0, n_chunks);
     const int rem = (int)(g_end - g);
-    if (rem == 3) process_tile<3, GUARD, POOL, STORE>(a, smem, cx, rg, ln, g, n0, n_chunks);
-    else if (rem == 2) process_tile<2, GUARD, POOL, STORE>(a, smem, cx, rg, ln, g, n0, n_chunks);
-    else if (rem == 1) process_tile<1, GUARD, POOL, STORE>(a, smem, cx, rg, ln, g, n0, n_chunks);
+    if (rem == 3) process_tile<3, GUARD, POOL, STORE, INBF, OUTBF>(a, smem, cx, rg, ln, g, n0, n_chunks);
+    else if (rem == 2) process_tile<2, GUARD, POOL, STORE, INBF, OUTBF>(a, smem, cx, rg, ln, g, n0, n_chunks);
+    else if (rem == 1) process_tile<1, GUARD, POOL, STORE, INBF, OUTBF>(a, smem, cx, rg, ln, g, n0, n_chunks);
 #ifdef XVEC_DIAG
     if (threadIdx.x == 0 && blockIdx.x < 8192) {
         __builtin_amdgcn_s_waitcnt(0);
@@ -381,9 +402,9 @@ __global__ __launch_bounds__(256, 2) void tdnn_f32_kernel(const TdnnArgs a) {
 #endif
 }
 
-template <bool GUARD, bool POOL, bool STORE>
+template <bool GUARD, bool POOL, bool STORE, bool INBF, bool OUTBF>
 static hipError_t launch_variant(const TdnnArgs& a, hipStream_t s) {
-    auto kern = tdnn_f32_kernel<GUARD, POOL, STORE>;
+    auto kern = tdnn_kernel<GUARD, POOL, STORE, INBF, OUTBF>;
     static bool attr_set = false;   // per-variant; benign if raced (idempotent)
     static int lds_pad = 0;
     if (!attr_set) {
@@ -406,14 +427,20 @@ extern "C" int xvec_diag_read(unsigned long long* host, int n_words) {
 }
 #endif
 
-hipError_t launch_tdnn_f32(const TdnnArgs& a, bool guard_a, bool fuse_pool, bool store_y, hipStream_t s) {
-    if (a.groups_total <= 0 || a.blocks_per_col <= 0 || a.blocks_per_col > a.groups_total)
+hipError_t launch_tdnn(const TdnnArgs& a, TdnnVariant v, hipStream_t s) {
+    if (a.groups_total <= 0 || a.blocks_per_col <= 0 || a.blocks_per_col > a.groups_total || (a.cpt & 1))
         return hipErrorInvalidValue;
-    if (fuse_pool) {
-        if (guard_a) return hipErrorInvalidValue;
-        return store_y ? launch_variant<false, true, true>(a, s) : launch_variant<false, true, false>(a, s);
+    switch (v) {
+        case TdnnVariant::kF32First: return launch_variant<true, false, true, false, false>(a, s);
+        case TdnnVariant::kF32: return launch_variant<false, false, true, false, false>(a, s);
+        case TdnnVariant::kF32Pool: return launch_variant<false, true, false, false, false>(a, s);
+        case TdnnVariant::kF32PoolStore: return launch_variant<false, true, true, false, false>(a, s);
+        case TdnnVariant::kF32FirstToBf16: return launch_variant<true, false, true, false, true>(a, s);
+        case TdnnVariant::kBf16: return launch_variant<false, false, true, true, true>(a, s);
+        case TdnnVariant::kBf16Pool: return launch_variant<false, true, false, true, false>(a, s);
+        case TdnnVariant::kBf16ToF32: return launch_variant<false, false, true, true, false>(a, s);
     }
-    return guard_a ? launch_variant<true, false, true>(a, s) : launch_variant<false, false, true>(a, s);
+    return hipErrorInvalidValue;
 }
 
 }  // namespace xvec

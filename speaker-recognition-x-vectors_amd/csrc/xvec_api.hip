@@ -45,6 +45,8 @@ struct xvec_handle {
     xvec_cfg cfg;
     int cin_pad;                       // input_size rounded up to 4 (row stride of layer-1 input)
     TdnnGeom geo[XVEC_NUM_TDNN];
+    TdnnGeom geo16[XVEC_NUM_TDNN];     // bf16 packing of layers 2-5: 64-element chunks (layer 1 stays fp32)
+    void* Wp16[XVEC_NUM_TDNN];
     float* Wp[XVEC_NUM_TDNN];
     float* vec[XVEC_NUM_TDNN];         // bias | scale | shift, n_pad each
     bool tdnn_loaded[XVEC_NUM_TDNN];
@@ -96,10 +98,12 @@ Plan make_plan(const xvec_handle* h, int64_t total, int B) {
     return p;
 }
 
-void fill_geometry(xvec_handle* h) {
+// chunk_pair = K elements of two 128-byte chunks (64 for fp32, 128 for bf16): the kernel's main
+// loop consumes whole chunk pairs per tap
+void fill_geometry(xvec_handle* h, TdnnGeom* geo, int chunk_pair) {
     const int hid = h->cfg.hidden_size;
     for (int i = 0; i < XVEC_NUM_TDNN; ++i) {
-        TdnnGeom& g = h->geo[i];
+        TdnnGeom& g = geo[i];
         g.src_taps = kCtxLen[i];
         g.src_cin = (i == 0) ? h->cfg.input_size : hid;
         g.cin = g.src_cin;
@@ -112,16 +116,15 @@ void fill_geometry(xvec_handle* h) {
             const int ldx = (i == 0) ? h->cin_pad : hid;
             g.n_taps = 1;
             g.tap_rows = 0;
-            g.tap_stride_src = (kCtxLen[i] == 1) ? round_up(g.cin, 2 * kBK) : ldx;
+            g.tap_stride_src = (kCtxLen[i] == 1) ? round_up(g.cin, chunk_pair) : ldx;
             g.kpt = (kCtxLen[i] == 1) ? g.cin : kCtxLen[i] * ldx;
         } else {
             g.n_taps = kCtxLen[i];
             g.tap_rows = kCtxDil[i];
             g.kpt = g.cin;
-            g.tap_stride_src = round_up(g.cin, 2 * kBK);
+            g.tap_stride_src = round_up(g.cin, chunk_pair);
         }
-        // whole chunk PAIRS per tap: the kernel's main loop consumes two 32-wide chunks per trip
-        g.kpt_pad = round_up(g.kpt, 2 * kBK);
+        g.kpt_pad = round_up(g.kpt, chunk_pair);
         g.k_pad = g.n_taps * g.kpt_pad;
     }
 }
@@ -143,15 +146,16 @@ struct StageTimer {
     }
 };
 
-// Launch one frame-level layer on flat rows.
-int run_tdnn(xvec_handle* h, int layer, const float* X, int ldx, int64_t x_rows, bool guard, float* Y,
-             const Plan& p, bool fuse_pool, bool store_y, float* part, const int64_t* offs_dev, int B,
-             int fixed_T, hipStream_t s) {
-    const TdnnGeom& g = h->geo[layer];
+// Launch one frame-level layer on flat rows.  The variant selects arithmetic and epilogue; bf16
+// variants use the bf16 packing (64-element chunks) of the layer's weights.
+int run_tdnn(xvec_handle* h, int layer, TdnnVariant v, const void* X, int ldx, int64_t x_rows, void* Y,
+             const Plan& p, float* part, const int64_t* offs_dev, int B, int fixed_T, hipStream_t s) {
+    const bool in16 = v == TdnnVariant::kBf16 || v == TdnnVariant::kBf16Pool || v == TdnnVariant::kBf16ToF32;
+    const TdnnGeom& g = in16 ? h->geo16[layer] : h->geo[layer];
     TdnnArgs a;
     memset(&a, 0, sizeof(a));
     a.X = X;
-    a.W = h->Wp[layer];
+    a.W = in16 ? h->Wp16[layer] : static_cast<const void*>(h->Wp[layer]);
     a.bias = h->vec[layer];
     a.scale = h->vec[layer] + g.n_pad;
     a.shift = h->vec[layer] + 2 * g.n_pad;
@@ -162,7 +166,7 @@ int run_tdnn(xvec_handle* h, int layer, const float* X, int ldx, int64_t x_rows,
     a.n_taps = g.n_taps;
     a.tap_rows = g.tap_rows;
     a.kpt = g.kpt;
-    a.cpt = g.kpt_pad / kBK;
+    a.cpt = g.kpt_pad / (in16 ? 2 * kBK : kBK);
     a.k_pad = g.k_pad;
     a.n_tiles = g.n_pad / 128;
     a.groups_total = (p.total + 31) / 32;
@@ -178,7 +182,7 @@ int run_tdnn(xvec_handle* h, int layer, const float* X, int ldx, int64_t x_rows,
     a.fixed_T = fixed_T;
     a.shrink = XVEC_TOTAL_CONTEXT;
     StageTimer t(h, T_L1 + layer, s);
-    HIP_TRY(launch_tdnn_f32(a, guard, fuse_pool, store_y, s));
+    HIP_TRY(launch_tdnn(a, v, s));
     return XVEC_OK;
 }
 
@@ -194,7 +198,7 @@ int check_loaded(const xvec_handle* h, int mode) {
 
 // x_rows: [total, ldx] packed rows (offs_host == nullptr: B utterances of fixed_T rows each)
 int forward_rows(xvec_handle* h, const float* x_rows, int ldx, const int64_t* offs_dev, int B, int fixed_T,
-                 const Plan& p, int mode, float* out, char* ws, hipStream_t s) {
+                 const Plan& p, int mode, int dtype, float* out, char* ws, hipStream_t s) {
     float* actA = reinterpret_cast<float*>(ws + p.actA);
     float* actB = reinterpret_cast<float*>(ws + p.actB);
     float* part = reinterpret_cast<float*>(ws + p.part);
@@ -203,13 +207,18 @@ int forward_rows(xvec_handle* h, const float* x_rows, int ldx, const int64_t* of
     float* s7 = reinterpret_cast<float*>(ws + p.seg7);
     const int nh = h->geo[0].n_pad;
     int rc;
-    // layer 1 reads the caller's rows: guarded against the end of the buffer and the K tail
-    if ((rc = run_tdnn(h, 0, x_rows, ldx, p.total, true, actA, p, false, true, nullptr, nullptr, B, fixed_T, s))) return rc;
-    if ((rc = run_tdnn(h, 1, actA, nh, 0, false, actB, p, false, true, nullptr, nullptr, B, fixed_T, s))) return rc;
-    if ((rc = run_tdnn(h, 2, actB, nh, 0, false, actA, p, false, true, nullptr, nullptr, B, fixed_T, s))) return rc;
-    if ((rc = run_tdnn(h, 3, actA, nh, 0, false, actB, p, false, true, nullptr, nullptr, B, fixed_T, s))) return rc;
-    // layer 5 with the statistics-pooling epilogue: its [frames,1500] output stays on chip
-    if ((rc = run_tdnn(h, 4, actB, nh, 0, false, nullptr, p, true, false, part, offs_dev, B, fixed_T, s))) return rc;
+    const bool b16 = dtype == XVEC_BF16;
+    // layer 1 reads the caller's rows (guarded against the end of the buffer and the K tail); it is
+    // fp32 MFMA in both modes (fp32 MFCC input, 2.4 % of the FLOPs), bf16 mode rounds its output.
+    // Layer 5 carries the statistics-pooling epilogue: its [frames,1500] output stays on chip.
+    const TdnnVariant v1 = b16 ? TdnnVariant::kF32FirstToBf16 : TdnnVariant::kF32First;
+    const TdnnVariant vm = b16 ? TdnnVariant::kBf16 : TdnnVariant::kF32;
+    const TdnnVariant v5 = b16 ? TdnnVariant::kBf16Pool : TdnnVariant::kF32Pool;
+    if ((rc = run_tdnn(h, 0, v1, x_rows, ldx, p.total, actA, p, nullptr, nullptr, B, fixed_T, s))) return rc;
+    if ((rc = run_tdnn(h, 1, vm, actA, nh, 0, actB, p, nullptr, nullptr, B, fixed_T, s))) return rc;
+    if ((rc = run_tdnn(h, 2, vm, actB, nh, 0, actA, p, nullptr, nullptr, B, fixed_T, s))) return rc;
+    if ((rc = run_tdnn(h, 3, vm, actA, nh, 0, actB, p, nullptr, nullptr, B, fixed_T, s))) return rc;
+    if ((rc = run_tdnn(h, 4, v5, actB, nh, 0, nullptr, p, part, offs_dev, B, fixed_T, s))) return rc;
     {
         StageTimer t(h, T_POOL, s);
         PoolFinalizeArgs f;
@@ -278,7 +287,7 @@ int common_checks(xvec_handle* h, const void* x, int B, int mode, int dtype, con
     if (B < 1) return fail(XVEC_ERR_ARG, "B must be >= 1 (got %d)", B);
     if (mode != XVEC_MODE_LOGITS && mode != XVEC_MODE_XVEC6 && mode != XVEC_MODE_XVEC7)
         return fail(XVEC_ERR_ARG, "unknown mode %d", mode);
-    if (dtype != XVEC_F32) return fail(XVEC_ERR_ARG, "dtype %d not supported by this build (fp32 only)", dtype);
+    if (dtype != XVEC_F32 && dtype != XVEC_BF16) return fail(XVEC_ERR_ARG, "unknown dtype %d", dtype);
     if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(ws) & 255))
         return fail(XVEC_ERR_ARG, "x must be 16-byte and workspace 256-byte aligned");
     return check_loaded(h, mode);
@@ -312,10 +321,12 @@ int xvec_create(const xvec_cfg* cfg, xvec_handle** out) {
         if (h->blocks_per_cu < 1) h->blocks_per_cu = 1;
     }
     h->cin_pad = round_up(cfg->input_size, 4);
-    fill_geometry(h);
+    fill_geometry(h, h->geo, 2 * kBK);
+    fill_geometry(h, h->geo16, 4 * kBK);
     for (int i = 0; i < XVEC_NUM_TDNN; ++i) {
         const TdnnGeom& g = h->geo[i];
-        if (hipMalloc(reinterpret_cast<void**>(&h->Wp[i]), (size_t)g.n_pad * g.k_pad * 4) != hipSuccess ||
+        if (hipMalloc(&h->Wp16[i], (size_t)h->geo16[i].n_pad * h->geo16[i].k_pad * 2) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void**>(&h->Wp[i]), (size_t)g.n_pad * g.k_pad * 4) != hipSuccess ||
             hipMalloc(reinterpret_cast<void**>(&h->vec[i]), (size_t)3 * g.n_pad * 4) != hipSuccess) {
             xvec_destroy(h);
             return fail(XVEC_ERR_HIP, "hipMalloc of packed weights failed");
@@ -347,6 +358,7 @@ void xvec_destroy(xvec_handle* h) {
     if (!h) return;
     for (int i = 0; i < XVEC_NUM_TDNN; ++i) {
         if (h->Wp[i]) (void)hipFree(h->Wp[i]);
+        if (h->Wp16[i]) (void)hipFree(h->Wp16[i]);
         if (h->vec[i]) (void)hipFree(h->vec[i]);
     }
     for (int i = 0; i < 3; ++i) {
@@ -375,6 +387,7 @@ int xvec_load_tdnn(xvec_handle* h, int layer, const float* weight, const float* 
     HIP_TRY(launch_pack_tdnn(weight, bias, bn_weight, bn_bias, bn_mean, bn_var, eps, g, h->Wp[layer],
                              h->vec[layer], h->vec[layer] + g.n_pad, h->vec[layer] + 2 * g.n_pad,
                              static_cast<hipStream_t>(stream)));
+    HIP_TRY(launch_pack_tdnn_bf16(weight, h->geo16[layer], h->Wp16[layer], static_cast<hipStream_t>(stream)));
     h->tdnn_loaded[layer] = true;
     return XVEC_OK;
 }
@@ -414,10 +427,10 @@ int xvec_forward(xvec_handle* h, const float* x, const int32_t* lengths_host, in
         if (h->cin_pad != C) {   // channel count not a multiple of 4: pad rows once
             StageTimer t(h, T_PACK, s);
             float* xp = reinterpret_cast<float*>(ws + p.xpad);
-            HIP_TRY(launch_pack_rows(x, nullptr, B, T, C, h->cin_pad, xp, s));
+            HIP_TRY(launch_pack_rows(x, nullptr, B, T, C, h->cin_pad, xp, false, s));
             rows = xp;
         }
-        return forward_rows(h, rows, h->cin_pad, nullptr, B, T, p, mode, out, ws, s);
+        return forward_rows(h, rows, h->cin_pad, nullptr, B, T, p, mode, dtype, out, ws, s);
     }
 
     // ragged: pack the valid frames, run the stack on sum(lengths) rows only
@@ -445,9 +458,9 @@ int xvec_forward(xvec_handle* h, const float* x, const int32_t* lengths_host, in
     float* xp = reinterpret_cast<float*>(ws + p.xpad);
     {
         StageTimer t(h, T_PACK, s);
-        HIP_TRY(launch_pack_rows(x, offs_dev, B, T, C, h->cin_pad, xp, s));
+        HIP_TRY(launch_pack_rows(x, offs_dev, B, T, C, h->cin_pad, xp, false, s));
     }
-    return forward_rows(h, xp, h->cin_pad, offs_dev, B, 0, p, mode, out, ws, s);
+    return forward_rows(h, xp, h->cin_pad, offs_dev, B, 0, p, mode, dtype, out, ws, s);
 }
 
 int xvec_forward_packed(xvec_handle* h, const float* x_packed, const int64_t* offsets_host, int32_t B, int mode,
@@ -476,17 +489,17 @@ int xvec_forward_packed(xvec_handle* h, const float* x_packed, const int64_t* of
         if (total > 0x7fffffff) return fail(XVEC_ERR_ARG, "too many frames");
         StageTimer t(h, T_PACK, s);
         float* xp = reinterpret_cast<float*>(ws + p.xpad);
-        HIP_TRY(launch_pack_rows(x_packed, nullptr, 1, (int)total, C, h->cin_pad, xp, s));
+        HIP_TRY(launch_pack_rows(x_packed, nullptr, 1, (int)total, C, h->cin_pad, xp, false, s));
         rows = xp;
     }
-    return forward_rows(h, rows, h->cin_pad, offs_dev, B, 0, p, mode, out, ws, s);
+    return forward_rows(h, rows, h->cin_pad, offs_dev, B, 0, p, mode, dtype, out, ws, s);
 }
 
 int xvec_tdnn_layer(xvec_handle* h, int layer, const float* x, int32_t B, int32_t T, int dtype, float* y,
                     void* workspace, size_t workspace_bytes, xvec_stream stream) {
     if (!h || layer < 0 || layer >= XVEC_NUM_TDNN) return fail(XVEC_ERR_ARG, "bad handle or layer %d", layer);
     if (!x || !y || !workspace) return fail(XVEC_ERR_ARG, "null tensor pointer");
-    if (dtype != XVEC_F32) return fail(XVEC_ERR_ARG, "dtype %d not supported by this build (fp32 only)", dtype);
+    if (dtype != XVEC_F32 && dtype != XVEC_BF16) return fail(XVEC_ERR_ARG, "unknown dtype %d", dtype);
     if (!h->tdnn_loaded[layer]) return fail(XVEC_ERR_STATE, "time_context_layers.%d weights not loaded", layer);
     const TdnnGeom& g = h->geo[layer];
     if (B < 1 || T <= g.ctx_span) return fail(XVEC_ERR_ARG, "need B>=1 and T>%d (got B=%d T=%d)", g.ctx_span, B, T);
@@ -495,14 +508,20 @@ int xvec_tdnn_layer(xvec_handle* h, int layer, const float* x, int32_t B, int32_
         return fail(XVEC_ERR_WORKSPACE, "workspace too small: %zu < %zu", workspace_bytes, p.bytes);
     hipStream_t s = static_cast<hipStream_t>(stream);
     char* ws = static_cast<char*>(workspace);
+    // bf16 mode: activations between layers are bf16 (layer 1 still reads fp32 MFCCs); the result is
+    // widened back to fp32 for the caller
+    const bool b16 = dtype == XVEC_BF16;
+    const bool in16 = b16 && layer > 0;
     // stage the compact input into the layer's native row layout (stride = producer's n_pad)
     const int ldx = (layer == 0) ? h->cin_pad : h->geo[layer - 1].n_pad;
-    float* xin = reinterpret_cast<float*>(ws + (layer == 0 ? p.xpad : p.actA));
-    HIP_TRY(launch_pack_rows(x, nullptr, B, T, g.src_cin, ldx, xin, s));
-    float* yflat = reinterpret_cast<float*>(ws + (layer == 4 ? p.act5 : p.actB));
-    int rc = run_tdnn(h, layer, xin, ldx, p.total, layer == 0, yflat, p, false, true, nullptr, nullptr, B, T, s);
+    void* xin = ws + (layer == 0 ? p.xpad : p.actA);
+    HIP_TRY(launch_pack_rows(x, nullptr, B, T, g.src_cin, ldx, xin, in16, s));
+    void* yflat = ws + (layer == 4 ? p.act5 : p.actB);
+    const TdnnVariant v = layer == 0 ? (b16 ? TdnnVariant::kF32FirstToBf16 : TdnnVariant::kF32First)
+                                     : (b16 ? TdnnVariant::kBf16 : TdnnVariant::kF32);
+    int rc = run_tdnn(h, layer, v, xin, ldx, p.total, yflat, p, nullptr, nullptr, B, T, s);
     if (rc) return rc;
-    HIP_TRY(launch_unpack_rows(yflat, g.n_pad, B, T, T - g.ctx_span, g.cout, y, s));
+    HIP_TRY(launch_unpack_rows(yflat, b16, g.n_pad, B, T, T - g.ctx_span, g.cout, y, s));
     return XVEC_OK;
 }
 

@@ -33,12 +33,12 @@ struct TdnnGeom {
 };
 
 struct TdnnArgs {
-    const float* X;     // [rows][ldx]
-    const float* W;     // packed [n_pad][k_pad]
+    const void* X;      // [rows][ldx]  fp32 or bf16
+    const void* W;      // packed [n_pad][k_pad]  fp32 or bf16
     const float* bias;  // [n_pad]
     const float* scale; // [n_pad]  folded BatchNorm: y = relu(v)*scale + shift
     const float* shift; // [n_pad]
-    float* Y;           // [m_pad][ldy]
+    void* Y;            // [m_pad][ldy]  fp32 or bf16
     int64_t x_rows;     // rows of X that may be read (guarded variant)
     int ldx, ldy;
     int n_taps, tap_rows, kpt, cpt;   // cpt = chunks per tap = kpt_pad / kBK
@@ -54,7 +54,18 @@ struct TdnnArgs {
     int shrink;               // pooled frames of utterance u = len_u - shrink
 };
 
-hipError_t launch_tdnn_f32(const TdnnArgs& a, bool guard_a, bool fuse_pool, bool store_y, hipStream_t s);
+// kernel instantiations: input/weight arithmetic x epilogue
+enum class TdnnVariant {
+    kF32First,        // fp32, guarded reads of the caller's rows (layer 1)
+    kF32,             // fp32 -> fp32
+    kF32Pool,         // fp32 -> pooling partials only (layer 5)
+    kF32PoolStore,    // fp32 -> fp32 + pooling partials
+    kF32FirstToBf16,  // layer 1 of the bf16 path: fp32 MFMA on the fp32 MFCCs, bf16 activations out
+    kBf16,            // bf16 -> bf16
+    kBf16Pool,        // bf16 -> pooling partials only
+    kBf16ToF32        // bf16 -> fp32 (per-layer test entry of layer 5)
+};
+hipError_t launch_tdnn(const TdnnArgs& a, TdnnVariant v, hipStream_t s);
 
 struct PoolArgs {
     const float* X;          // [rows][ld]
@@ -84,11 +95,12 @@ hipError_t launch_affine_f32(const float* x, const float* W, const float* b, flo
 hipError_t launch_pack_tdnn(const float* W, const float* bias, const float* g, const float* be,
                             const float* mu, const float* var, float eps, const TdnnGeom& geo,
                             float* Wp, float* bias_p, float* scale_p, float* shift_p, hipStream_t s);
-// x[B,T,C] (+lengths) -> packed rows [sum len, c_pad] ; offsets on device
+hipError_t launch_pack_tdnn_bf16(const float* W, const TdnnGeom& geo, void* Wp16, hipStream_t s);
+// x[B,T,C] (+lengths) -> packed rows [sum len, c_pad] (fp32 or bf16); offsets on device
 hipError_t launch_pack_rows(const float* x, const int64_t* offsets, int B, int T, int C, int c_pad,
-                            float* out, hipStream_t s);
-// flat [rows, ld] -> compact y[B, T_out, C]
-hipError_t launch_unpack_rows(const float* flat, int ld, int B, int T_in, int T_out, int C, float* y,
-                              hipStream_t s);
+                            void* out, bool out_bf16, hipStream_t s);
+// flat [rows, ld] (fp32 or bf16) -> compact fp32 y[B, T_out, C]
+hipError_t launch_unpack_rows(const void* flat, bool in_bf16, int ld, int B, int T_in, int T_out, int C,
+                              float* y, hipStream_t s);
 
 }  // namespace xvec

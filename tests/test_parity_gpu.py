@@ -233,3 +233,51 @@ def test_errors_are_loud(gpu_model):
             gpu_model(torch.zeros(1, 300, 24, device=DEV))
     finally:
         gpu_model.eval()
+
+
+# ------------------------------------------------------------------------------- bf16 path
+def _bf16_model(sd42):
+    import xvector_amd as xa
+    m = xa.XVectorModel(precision="bf16")
+    m.load_state_dict(sd42)
+    return m.to(DEV)
+
+
+def test_bf16_layers_vs_fp32(gpu_model, sd42, synth):
+    """BASELINE config 4: bf16 activations/weights, fp32 accumulation -- each layer within 1e-2
+    (norm-wise per frame) of the fp32 layer on the same input.  Measured: 2.4e-3 norm-wise; single
+    post-ReLU elements reach 1.05e-2 of (mean|ref|+|ref|), hence 2e-2 element-wise for one layer;
+    the end-to-end check below holds the full 1e-2 form (measured 9e-4 / 3e-3)."""
+    m16 = _bf16_model(sd42)
+    h = _gpu(synth.make_mfcc(3, 150, seed=21))
+    for i in range(5):
+        ref = gpu_model.time_context_layers[i](h)
+        got = m16.time_context_layers[i](h)
+        assert_parity(got, ref, 1e-2, f"bf16 layer {i}", elem_tol=2e-2)
+        h = ref
+
+
+@pytest.mark.parametrize("B,T", [(1, 299), (8, 300), (256, 300)])
+def test_bf16_full_path_vs_fp32(gpu_model, sd42, synth, B, T):
+    m16 = _bf16_model(sd42)
+    x = _gpu(synth.make_mfcc(B, T, seed=31))
+    assert_parity(m16.extract_x_vec(x), gpu_model.extract_x_vec(x), 1e-2, "bf16 xvec6")
+    assert_parity(m16(x), gpu_model(x), 1e-2, "bf16 logits")
+    if B == 8:     # and against the reference's own fp32 CPU result
+        with torch.no_grad():
+            ref = oracle.extract_x_vec(x.cpu(), float_params(sd42))
+        assert_parity(m16.extract_x_vec(x), ref, 1e-2, "bf16 xvec6 vs oracle")
+
+
+def test_bf16_ragged_and_tiny(sd42, synth):
+    import xvector_amd as xa
+    m16 = _bf16_model(sd42)
+    g = load_golden("g5_ragged.npz")
+    x = _gpu(synth.make_mfcc(3, 1000, seed=int(g["seed_x"])))
+    assert_parity(m16.extract_x_vec(x, lengths=g["lengths"].tolist()), g["xvec6"], 1e-2, "bf16 ragged")
+    gt = load_golden("g6_tiny.npz")
+    sd = {k[len("bn/w/"):]: torch.from_numpy(gt[k]) for k in gt.files if k.startswith("bn/w/")}
+    mt = xa.XVectorModel(input_size=24, hidden_size=32, num_classes=10, x_vector_size=16, precision="bf16")
+    mt.load_state_dict(sd)
+    mt = mt.to(DEV)
+    assert_parity(mt.extract_x_vec(_gpu(gt["bn/x"])), gt["bn/xvec6"], 1e-2, "bf16 tiny")

@@ -37,29 +37,22 @@ __global__ __launch_bounds__(256) void stat_pool_kernel(const PoolArgs a) {
     const int ch = (blockIdx.x * 64 + lane) * VEC;
     const bool active = ch < a.C;
 
-    int64_t off;
-    int n;
-    if (a.offsets) {
-        off = a.offsets[u];
-        n = (int)(a.offsets[u + 1] - off) - a.shrink;
-    } else {
-        off = (int64_t)u * a.fixed_T;
-        n = a.lengths ? a.lengths[u] : a.fixed_n;
-    }
+    const int64_t off = (int64_t)u * a.T;
+    const int n = a.lengths ? a.lengths[u] : a.T;
 
     float K[VEC], s1[VEC], s2[VEC];
 #pragma unroll
     for (int k = 0; k < VEC; ++k) { K[k] = 0.f; s1[k] = 0.f; s2[k] = 0.f; }
     if (active && n > 0) {
-        const float* base = a.X + off * (int64_t)a.ld + ch;
+        const float* base = a.X + off * (int64_t)a.C + ch;
         ld<VEC>(base, K);
         int f = wave;
         for (; f + 12 < n; f += 16) {   // 4 independent rows in flight per wave
             float v0[VEC], v1[VEC], v2[VEC], v3[VEC];
-            ld<VEC>(base + (int64_t)f * a.ld, v0);
-            ld<VEC>(base + (int64_t)(f + 4) * a.ld, v1);
-            ld<VEC>(base + (int64_t)(f + 8) * a.ld, v2);
-            ld<VEC>(base + (int64_t)(f + 12) * a.ld, v3);
+            ld<VEC>(base + (int64_t)f * a.C, v0);
+            ld<VEC>(base + (int64_t)(f + 4) * a.C, v1);
+            ld<VEC>(base + (int64_t)(f + 8) * a.C, v2);
+            ld<VEC>(base + (int64_t)(f + 12) * a.C, v3);
 #pragma unroll
             for (int k = 0; k < VEC; ++k) {
                 const float d0 = v0[k] - K[k], d1 = v1[k] - K[k], d2 = v2[k] - K[k], d3 = v3[k] - K[k];
@@ -69,7 +62,7 @@ __global__ __launch_bounds__(256) void stat_pool_kernel(const PoolArgs a) {
         }
         for (; f < n; f += 4) {
             float v0[VEC];
-            ld<VEC>(base + (int64_t)f * a.ld, v0);
+            ld<VEC>(base + (int64_t)f * a.C, v0);
 #pragma unroll
             for (int k = 0; k < VEC; ++k) {
                 const float d0 = v0[k] - K[k];
@@ -103,7 +96,7 @@ __global__ __launch_bounds__(256) void stat_pool_kernel(const PoolArgs a) {
 
 hipError_t launch_stat_pool(const PoolArgs& a, hipStream_t s) {
     if (a.B <= 0 || a.C <= 0) return hipSuccess;
-    const bool vec4 = (a.C % 4 == 0) && (a.ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.X) & 15) == 0);
+    const bool vec4 = (a.C % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.X) & 15) == 0);
     if (vec4) {
         dim3 grid((a.C / 4 + 63) / 64, a.B);
         stat_pool_kernel<4><<<grid, 256, 0, s>>>(a);
@@ -120,9 +113,7 @@ __global__ __launch_bounds__(256) void pool_finalize_kernel(const PoolFinalizeAr
     const int u = blockIdx.y;
     const int ch = blockIdx.x * 256 + threadIdx.x;
     if (ch >= a.C) return;
-    const int64_t off = a.offsets ? a.offsets[u] : (int64_t)u * a.fixed_T;
-    const int64_t len = a.offsets ? (a.offsets[u + 1] - off) : (int64_t)a.fixed_T;
-    const int64_t end = off + len - a.shrink;          // pooled rows are [off, end)
+    const int64_t off = row_off(a.map, u), end = row_off(a.map, u + 1);   // pooled rows are [off, end)
     float n = 0.f, mean = 0.f, m2 = 0.f;
     for (int64_t sub = off / a.sub_rows; sub * a.sub_rows < end; ++sub) {
         const int64_t lo = sub * a.sub_rows > off ? sub * a.sub_rows : off;
@@ -142,8 +133,8 @@ __global__ __launch_bounds__(256) void pool_finalize_kernel(const PoolFinalizeAr
 }
 
 hipError_t launch_pool_finalize(const PoolFinalizeArgs& a, hipStream_t s) {
-    if (a.B <= 0) return hipSuccess;
-    dim3 grid((a.C + 255) / 256, a.B);
+    if (a.map.n_utts <= 0) return hipSuccess;
+    dim3 grid((a.C + 255) / 256, a.map.n_utts);
     pool_finalize_kernel<<<grid, 256, 0, s>>>(a);
     return hipGetLastError();
 }

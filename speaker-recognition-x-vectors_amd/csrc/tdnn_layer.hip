@@ -60,45 +60,44 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 }
 
 // Fused statistics-pooling partial (main.py:59-63) of one 32-row group held in one accumulator:
-// for every utterance overlapping flat rows [row_g, row_g+32), the mean and M2 (sum of squared
-// deviations about that mean) of this lane's column over the utterance's valid pooled frames.
+// for every utterance overlapping compact rows [row_g, row_g+32), the mean and M2 (sum of squared
+// deviations about that mean) of this lane's column over the utterance's frames in the group.
 __device__ __forceinline__ void pool_group(const TdnnArgs& a, const f32x16& v, int64_t row_g, int h, int col) {
-    int u;
-    if (a.offsets == nullptr) {
-        u = (int)(row_g / a.fixed_T);
-    } else {
-        int lo = 0, hi = a.n_utts;            // largest u with offsets[u] <= row_g
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (a.offsets[mid] <= row_g) lo = mid; else hi = mid;
-        }
-        u = lo;
-    }
     const int64_t grp = row_g >> 5;
-    for (; u < a.n_utts; ++u) {
-        const int64_t off = a.offsets ? a.offsets[u] : (int64_t)u * a.fixed_T;
+    for (int u = utt_of_row(a.out_map, row_g); u < a.out_map.n_utts; ++u) {
+        const int64_t off = row_off(a.out_map, u);
         if (off >= row_g + 32) break;
-        const int64_t len = a.offsets ? (a.offsets[u + 1] - off) : (int64_t)a.fixed_T;
+        const int64_t end = row_off(a.out_map, u + 1);
         const int64_t lo_r = off > row_g ? off : row_g;
-        int64_t hi_r = off + len - a.shrink;
-        if (hi_r > row_g + 32) hi_r = row_g + 32;
+        const int64_t hi_r = end < row_g + 32 ? end : row_g + 32;
         if (hi_r <= lo_r) continue;
         const int lo_l = (int)(lo_r - row_g), hi_l = (int)(hi_r - row_g);   // local rows [lo_l, hi_l)
-        const float inv_cnt = 1.f / (float)(hi_l - lo_l);
-        float s = 0.f;
+        float s = 0.f, m2 = 0.f, mean;
+        if (lo_l == 0 && hi_l == 32) {        // whole group inside one utterance: no masks
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int lr = (e & 3) + 8 * (e >> 2) + 4 * h;
-            s += (lr >= lo_l && lr < hi_l) ? v[e] : 0.f;
-        }
-        s += __shfl_xor(s, 32);
-        const float mean = s * inv_cnt;
-        float m2 = 0.f;
+            for (int e = 0; e < 16; ++e) s += v[e];
+            s += __shfl_xor(s, 32);
+            mean = s * (1.f / 32.f);
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int lr = (e & 3) + 8 * (e >> 2) + 4 * h;
-            const float d = v[e] - mean;
-            m2 += (lr >= lo_l && lr < hi_l) ? d * d : 0.f;
+            for (int e = 0; e < 16; ++e) {
+                const float d = v[e] - mean;
+                m2 = fmaf(d, d, m2);
+            }
+        } else {
+            const float inv_cnt = 1.f / (float)(hi_l - lo_l);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int lr = (e & 3) + 8 * (e >> 2) + 4 * h;
+                s += (lr >= lo_l && lr < hi_l) ? v[e] : 0.f;
+            }
+            s += __shfl_xor(s, 32);
+            mean = s * inv_cnt;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int lr = (e & 3) + 8 * (e >> 2) + 4 * h;
+                const float d = v[e] - mean;
+                m2 += (lr >= lo_l && lr < hi_l) ? d * d : 0.f;
+            }
         }
         m2 += __shfl_xor(m2, 32);
         if (h == 0) {
@@ -119,8 +118,13 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 struct Ctx {
     __amdgpu_buffer_rsrc_t xrsrc;   // X + m0*ldx  (tile the load stream is in)
     __amdgpu_buffer_rsrc_t wrsrc;   // W + n0*k_pad
-    int x_toff;          // (r0*ldx + c*4) * 4 bytes  (per thread)
-    int w_toff;          // (r0*k_pad + c*4) * 4 bytes
+    int x_base;          // r0*ldx*ES + c*16 bytes    (per thread)
+    int ur0, ur1, ur2, ur3;   // u(row r0+32j of the tile)*span: rows to add to re-base into the input layout
+    int xo0, xo1, xo2, xo3;   // x_base + ur_j*ldx*ES
+    int w_toff;          // r0*k_pad*ES + c*16 bytes
+    int r0;
+    int u_tile;          // utterance holding row m0 (block-uniform), and the first row of the next one
+    int64_t off_next;
     int64_t m0;          // first flat row of the tile the load stream is in
     int64_t g_s, g_end;  // that tile's first row group; end of this block's row range
     int tap, kc, itl;    // next chunk to fetch: (tap, kc) and its linear index within the tile
@@ -145,6 +149,42 @@ __device__ __forceinline__ float4 buf_load16(__amdgpu_buffer_rsrc_t rsrc, int vo
     return make_float4(f.x, f.y, f.z, f.w);
 }
 
+// per-thread input offsets of the four staging rows (r0 + 32j) of the tile the stream is in: the
+// compact output row p of utterance u reads input rows p + u*span (+ tap shift).  The utterance of
+// the tile's first row is tracked incrementally (cx.u_tile / cx.off_next: tiles only move forward),
+// each row then walks at most a few utterance boundaries -- no division per tile.
+__device__ __forceinline__ int rebase_rows(const TdnnArgs& a, const Ctx& cx, int64_t p) {
+    int u = cx.u_tile;
+    int64_t nxt = cx.off_next;
+    while (p >= nxt && u < a.out_map.n_utts - 1) {
+        ++u;
+        nxt = row_off(a.out_map, u + 1);
+    }
+    return u * a.span;
+}
+
+__device__ __forceinline__ void set_tile_rows(const TdnnArgs& a, Ctx& cx) {
+    if (a.span == 0) {
+        cx.ur0 = cx.ur1 = cx.ur2 = cx.ur3 = 0;
+        cx.xo0 = cx.xo1 = cx.xo2 = cx.xo3 = cx.x_base;
+        return;
+    }
+    while (cx.m0 >= cx.off_next && cx.u_tile < a.out_map.n_utts - 1) {   // block-uniform
+        ++cx.u_tile;
+        cx.off_next = row_off(a.out_map, cx.u_tile + 1);
+    }
+    const int64_t p = cx.m0 + cx.r0;
+    const int rb = a.ldx * cx.es;
+    cx.ur0 = rebase_rows(a, cx, p);
+    cx.ur1 = rebase_rows(a, cx, p + 32);
+    cx.ur2 = rebase_rows(a, cx, p + 64);
+    cx.ur3 = rebase_rows(a, cx, p + 96);
+    cx.xo0 = cx.x_base + cx.ur0 * rb;
+    cx.xo1 = cx.x_base + cx.ur1 * rb;
+    cx.xo2 = cx.x_base + cx.ur2 * rb;
+    cx.xo3 = cx.x_base + cx.ur3 * rb;
+}
+
 // Step the load stream to the next K-chunk.  The stream is continuous over the block's tiles:
 // after the last chunk of a tile it moves to chunk 0 of the next tile (same channel column, next
 // <=4 row groups), so a tile's first chunks are already in flight / in LDS when its MFMAs start
@@ -164,6 +204,7 @@ __device__ __forceinline__ void advance(const TdnnArgs& a, Ctx& cx, int n_chunks
             cx.g_s = g_next;
             cx.m0 = g_next * 32;
             cx.xrsrc = make_rsrc(static_cast<const char*>(a.X) + cx.m0 * (int64_t)a.ldx * cx.es);
+            set_tile_rows(a, cx);
             cx.itl = 0;
             cx.kc = 0;
             cx.tap = 0;
@@ -193,11 +234,12 @@ __device__ __forceinline__ void advance(const TdnnArgs& a, Ctx& cx, int n_chunks
         const int row_shift = cx.tap * a.tap_rows;                                                        \
         const int soff = ((row_shift + 32 * i_) * a.ldx + cx.kc * BKE) * ES;                              \
         if (GUARD) {                                                                                      \
-            const bool ok = (cx.m0 + r0 + 32 * i_ + row_shift < a.x_rows) && (cx.kc * BKE + c * (16 / ES) < a.kpt); \
-            const float4 t = buf_load16(cx.xrsrc, ok ? cx.x_toff : 0, ok ? soff : 0);                     \
+            const bool ok = (cx.m0 + r0 + 32 * i_ + cx.ur##i_ + row_shift < a.x_rows) &&                  \
+                            (cx.kc * BKE + c * (16 / ES) < a.kpt);                                        \
+            const float4 t = buf_load16(cx.xrsrc, ok ? cx.xo##i_ : 0, ok ? soff : 0);                     \
             rg.sA##i_##_##n_ = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);                                     \
         } else {                                                                                          \
-            rg.sA##i_##_##n_ = buf_load16(cx.xrsrc, cx.x_toff, soff);                                        \
+            rg.sA##i_##_##n_ = buf_load16(cx.xrsrc, cx.xo##i_, soff);                                        \
         }                                                                                                 \
     }
 #define XV_GLD_B(j_, n_)                                                                                  \
@@ -272,7 +314,8 @@ struct Regs {
 };
 
 struct Lane {
-    int h, sw, a_rd, b_rd, st_off, r0, c, col_in_tile;
+    int h, sw, a_rd, b_rd, st_off, r0, c, col;
+    float bias, scale, shift;   // epilogue constants of this lane's channel (fixed for the whole block)
 };
 
 // Once per block: chunk 0 of the first tile -> LDS buffer 0, its first fragments -> set 0,
@@ -317,8 +360,8 @@ __device__ __forceinline__ void process_tile(const TdnnArgs& a, float* smem, Ctx
     const int64_t m0 = g0 * 32;
     // ---- epilogue: bias + ReLU + folded BatchNorm (tdnn_layer.py:30-39)
     // accumulator element e of lane (r, h): row = (e&3) + 8*(e>>2) + 4*h, col = r
-    const int col = n0 + ln.col_in_tile;
-    const float bi = a.bias[col], sc = a.scale[col], sh = a.shift[col];
+    const int col = ln.col;
+    const float bi = ln.bias, sc = ln.scale, sh = ln.shift;
 #define XV_EPI(i_)                                                                                        \
     if constexpr (G > i_) {                                                                               \
         _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                                  \
@@ -367,7 +410,10 @@ __global__ __launch_bounds__(256, 2) void tdnn_kernel(const TdnnArgs a) {
     ln.sw = (r >> 1) & 7;
     ln.a_rd = r * kBK;
     ln.b_rd = kBM * kBK + (wave * 32 + r) * kBK;
-    ln.col_in_tile = wave * 32 + r;
+    ln.col = n0 + wave * 32 + r;
+    ln.bias = a.bias[ln.col];
+    ln.scale = a.scale[ln.col];
+    ln.shift = a.shift[ln.col];
 
     Ctx cx;
     cx.g_s = g_begin;
@@ -377,8 +423,12 @@ __global__ __launch_bounds__(256, 2) void tdnn_kernel(const TdnnArgs a) {
     cx.es = ES;
     cx.xrsrc = make_rsrc(static_cast<const char*>(a.X) + cx.m0 * (int64_t)a.ldx * ES);
     cx.wrsrc = make_rsrc(static_cast<const char*>(a.W) + (int64_t)n0 * a.k_pad * ES);
-    cx.x_toff = ln.r0 * a.ldx * ES + ln.c * 16;
+    cx.x_base = ln.r0 * a.ldx * ES + ln.c * 16;
     cx.w_toff = ln.r0 * a.k_pad * ES + ln.c * 16;
+    cx.r0 = ln.r0;
+    cx.u_tile = utt_of_row(a.out_map, cx.m0);
+    cx.off_next = row_off(a.out_map, cx.u_tile + 1);
+    set_tile_rows(a, cx);
     cx.tap = 0;
     cx.kc = 0;
     cx.itl = 0;

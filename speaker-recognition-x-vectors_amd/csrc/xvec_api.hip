@@ -149,7 +149,7 @@ struct StageTimer {
 // Launch one frame-level layer on flat rows.  The variant selects arithmetic and epilogue; bf16
 // variants use the bf16 packing (64-element chunks) of the layer's weights.
 int run_tdnn(xvec_handle* h, int layer, TdnnVariant v, const void* X, int ldx, int64_t x_rows, void* Y,
-             const Plan& p, float* part, const int64_t* offs_dev, int B, int fixed_T, hipStream_t s) {
+             int64_t rows_out, const RowMap& out_map, float* part, hipStream_t s) {
     const bool in16 = v == TdnnVariant::kBf16 || v == TdnnVariant::kBf16Pool || v == TdnnVariant::kBf16ToF32;
     const TdnnGeom& g = in16 ? h->geo16[layer] : h->geo[layer];
     TdnnArgs a;
@@ -169,7 +169,7 @@ int run_tdnn(xvec_handle* h, int layer, TdnnVariant v, const void* X, int ldx, i
     a.cpt = g.kpt_pad / (in16 ? 2 * kBK : kBK);
     a.k_pad = g.k_pad;
     a.n_tiles = g.n_pad / 128;
-    a.groups_total = (p.total + 31) / 32;
+    a.groups_total = (rows_out + 31) / 32;
     {
         int64_t per_col = (int64_t)h->num_cu * h->blocks_per_cu / a.n_tiles;
         if (per_col < 1) per_col = 1;
@@ -177,10 +177,8 @@ int run_tdnn(xvec_handle* h, int layer, TdnnVariant v, const void* X, int ldx, i
         a.blocks_per_col = (int)per_col;
     }
     a.pool_part = part;
-    a.offsets = offs_dev;
-    a.n_utts = B;
-    a.fixed_T = fixed_T;
-    a.shrink = XVEC_TOTAL_CONTEXT;
+    a.out_map = out_map;
+    a.span = h->geo[layer].ctx_span;
     StageTimer t(h, T_L1 + layer, s);
     HIP_TRY(launch_tdnn(a, v, s));
     return XVEC_OK;
@@ -214,22 +212,34 @@ int forward_rows(xvec_handle* h, const float* x_rows, int ldx, const int64_t* of
     const TdnnVariant v1 = b16 ? TdnnVariant::kF32FirstToBf16 : TdnnVariant::kF32First;
     const TdnnVariant vm = b16 ? TdnnVariant::kBf16 : TdnnVariant::kF32;
     const TdnnVariant v5 = b16 ? TdnnVariant::kBf16Pool : TdnnVariant::kF32Pool;
-    if ((rc = run_tdnn(h, 0, v1, x_rows, ldx, p.total, actA, p, nullptr, nullptr, B, fixed_T, s))) return rc;
-    if ((rc = run_tdnn(h, 1, vm, actA, nh, 0, actB, p, nullptr, nullptr, B, fixed_T, s))) return rc;
-    if ((rc = run_tdnn(h, 2, vm, actB, nh, 0, actA, p, nullptr, nullptr, B, fixed_T, s))) return rc;
-    if ((rc = run_tdnn(h, 3, vm, actA, nh, 0, actB, p, nullptr, nullptr, B, fixed_T, s))) return rc;
-    if ((rc = run_tdnn(h, 4, v5, actB, nh, 0, nullptr, p, part, offs_dev, B, fixed_T, s))) return rc;
+    // every layer's output is compact: utterance u keeps len_u - cum frames after `cum` frames of
+    // context have been consumed (4, 8, 14, 14, 14 after layers 1..5)
+    RowMap map;
+    map.offsets = offs_dev;
+    map.n_utts = B;
+    map.fixed_T = fixed_T;
+    map.cum = 0;
+    void* bufs[2] = {actA, actB};
+    const void* in = x_rows;
+    int ld_in = ldx;
+    for (int l = 0; l < XVEC_NUM_TDNN; ++l) {
+        map.cum += h->geo[l].ctx_span;
+        const int64_t rows_out = p.total - (int64_t)B * map.cum;
+        const TdnnVariant v = l == 0 ? v1 : l == 4 ? v5 : vm;
+        void* out_buf = l == 4 ? nullptr : bufs[l & 1];
+        if ((rc = run_tdnn(h, l, v, in, ld_in, l == 0 ? p.total : 0, out_buf, rows_out, map, l == 4 ? part : nullptr, s)))
+            return rc;
+        in = out_buf;
+        ld_in = nh;
+    }
     {
         StageTimer t(h, T_POOL, s);
         PoolFinalizeArgs f;
         f.part = part;
         f.out = pooled;
-        f.offsets = offs_dev;
-        f.B = B;
+        f.map = map;
         f.C = XVEC_POOL_CHANNELS;
         f.n_pad = h->geo[4].n_pad;
-        f.fixed_T = fixed_T;
-        f.shrink = XVEC_TOTAL_CONTEXT;
         f.sub_rows = 32;
         HIP_TRY(launch_pool_finalize(f, s));
     }
@@ -519,9 +529,15 @@ int xvec_tdnn_layer(xvec_handle* h, int layer, const float* x, int32_t B, int32_
     void* yflat = ws + (layer == 4 ? p.act5 : p.actB);
     const TdnnVariant v = layer == 0 ? (b16 ? TdnnVariant::kF32FirstToBf16 : TdnnVariant::kF32First)
                                      : (b16 ? TdnnVariant::kBf16 : TdnnVariant::kF32);
-    int rc = run_tdnn(h, layer, v, xin, ldx, p.total, yflat, p, nullptr, nullptr, B, T, s);
+    RowMap map;
+    map.offsets = nullptr;
+    map.n_utts = B;
+    map.fixed_T = T;
+    map.cum = g.ctx_span;
+    const int To = T - g.ctx_span;
+    int rc = run_tdnn(h, layer, v, xin, ldx, p.total, yflat, (int64_t)B * To, map, nullptr, s);
     if (rc) return rc;
-    HIP_TRY(launch_unpack_rows(yflat, b16, g.n_pad, B, T, T - g.ctx_span, g.cout, y, s));
+    HIP_TRY(launch_unpack_rows(yflat, b16, g.n_pad, B, To, To, g.cout, y, s));
     return XVEC_OK;
 }
 
@@ -536,10 +552,8 @@ int xvec_stat_pool(const float* x, const int32_t* lengths_dev, int32_t B, int32_
     a.out = out;
     a.lengths = lengths_dev;
     a.B = B;
+    a.T = T;
     a.C = C;
-    a.ld = C;
-    a.fixed_T = T;
-    a.fixed_n = T;
     HIP_TRY(launch_stat_pool(a, static_cast<hipStream_t>(stream)));
     return XVEC_OK;
 }

@@ -12,11 +12,39 @@ constexpr int kRowPadTail = 136; // readable rows past M_pad: a 4-group look-ahe
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 inline int64_t round_up64(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 
-// One frame-level layer as an implicit GEMM over the FLAT frame axis:
-//   Y[p, n] = bn( relu( sum_{tap,c} X[p + tap*tap_rows, c] * W[n, tap, c] + bias[n] ) )
-// for every flat row p of the packed batch.  Rows whose receptive field leaves their
-// utterance are computed too (garbage in, garbage out) and never read by a valid row
-// of the next layer -- see DESIGN.md "flat frame axis".
+// Row layout of one layer's activations: the batch is ONE matrix of frames, utterance u in rows
+//   [row_off(u), row_off(u+1)),  row_off(u) = (offsets ? offsets[u] : u*fixed_T) - u*cum
+// where offsets / fixed_T describe the rows of the layer-1 INPUT and cum is the number of frames
+// the valid convolutions have consumed so far (0, 4, 8, 14, 14, 14).  Every layer's output is
+// compact: only valid frames exist, nothing is computed for frames whose context is missing.
+struct RowMap {
+    const int64_t* offsets;   // device [n_utts+1], or nullptr for fixed length
+    int n_utts;
+    int fixed_T;
+    int cum;
+};
+#ifdef __HIPCC__
+__device__ __forceinline__ int64_t row_off(const RowMap& m, int u) {
+    return (m.offsets ? m.offsets[u] : (int64_t)u * m.fixed_T) - (int64_t)u * m.cum;
+}
+// utterance holding compact row p (clamped to the last utterance for rows past the end)
+__device__ __forceinline__ int utt_of_row(const RowMap& m, int64_t p) {
+    if (m.offsets == nullptr) {
+        const int64_t u = p / (m.fixed_T - m.cum);
+        return (int)(u < m.n_utts - 1 ? u : m.n_utts - 1);
+    }
+    int lo = 0, hi = m.n_utts;                // largest u with row_off(u) <= p
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (row_off(m, mid) <= p) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+#endif
+
+// One frame-level layer as an implicit GEMM over the flat frame axis:
+//   Y[p, n] = bn( relu( sum_{tap,c} X[p + u(p)*span + tap*tap_rows, c] * W[n, tap, c] + bias[n] ) )
+// for every compact output row p; u(p)*span re-bases the row into the (longer) input layout.
 struct TdnnGeom {
     int cin;        // valid input channels per tap
     int cout;       // valid output channels
@@ -46,12 +74,10 @@ struct TdnnArgs {
     int n_tiles;              // 128-channel columns
     int blocks_per_col;       // persistent blocks per column; grid = n_tiles * blocks_per_col
     int64_t groups_total;     // 32-row groups of the flat frame axis (ceil(rows / 32))
+    RowMap out_map;           // row layout of THIS layer's output
+    int span;                 // frames this layer consumes (c[-1]-c[0]): input row = p + u(p)*span
     // fused statistics-pooling epilogue (layer 5)
     float* pool_part;         // [slots][2][n_pad] (mean, M2) per (32-row group, utterance)
-    const int64_t* offsets;   // device [B+1] row offsets, or nullptr for fixed length
-    int n_utts;
-    int fixed_T;              // frames per utterance when offsets == nullptr
-    int shrink;               // pooled frames of utterance u = len_u - shrink
 };
 
 // kernel instantiations: input/weight arithmetic x epilogue
@@ -68,22 +94,18 @@ enum class TdnnVariant {
 hipError_t launch_tdnn(const TdnnArgs& a, TdnnVariant v, hipStream_t s);
 
 struct PoolArgs {
-    const float* X;          // [rows][ld]
+    const float* X;          // [B][T][C]
     float* out;              // [B][2C]
-    const int64_t* offsets;  // device [B+1] or nullptr
-    const int32_t* lengths;  // device [B] or nullptr (stand-alone masked pooling on [B,T,C])
-    int B, C, ld;
-    int fixed_T;             // row stride between utterances when offsets == nullptr
-    int fixed_n;             // frames pooled per utterance when neither offsets nor lengths
-    int shrink;              // with offsets: n_u = len_u - shrink; with lengths: n_u = lengths[u]
+    const int32_t* lengths;  // device [B] valid frames per utterance, or nullptr (all T)
+    int B, T, C;
 };
 hipError_t launch_stat_pool(const PoolArgs& a, hipStream_t s);
 
 struct PoolFinalizeArgs {
     const float* part;       // [slots][2][n_pad]
     float* out;              // [B][2C]
-    const int64_t* offsets;
-    int B, C, n_pad, fixed_T, shrink, sub_rows;
+    RowMap map;              // row layout of the pooled activation (layer 5 output)
+    int C, n_pad, sub_rows;
 };
 hipError_t launch_pool_finalize(const PoolFinalizeArgs& a, hipStream_t s);
 

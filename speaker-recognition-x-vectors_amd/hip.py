@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libxvec_hip.so")
+# XVEC_LIB: development override (A/B runs of two builds on one GPU box); the default is the in-tree build
+LIB_PATH = os.environ.get("XVEC_LIB") or os.path.join(_HERE, "libxvec_hip.so")
 
 OK, ERR_ARG, ERR_HIP, ERR_STATE, ERR_WORKSPACE = 0, 1, 2, 3, 4
 F32, BF16 = 0, 1

@@ -81,12 +81,13 @@ hipError_t launch_pack_rows(const float* x, const int64_t* offsets, int B, int T
                             void* out, bool out_bf16, hipStream_t s) {
     if (B <= 0) return hipSuccess;
     const int64_t per = (int64_t)T * c_pad;
-    int gx = (int)((per + 255) / 256);
-    if (gx > 64) gx = 64;
+    int64_t gx = (per + 255) / 256;
+    const int64_t cap = B >= 32 ? 64 : 2048 / B;   // enough blocks to fill the chip for small B
+    if (gx > cap) gx = cap;
     if (out_bf16)
-        pack_rows_kernel<__bf16><<<dim3(gx, B), 256, 0, s>>>(x, offsets, T, C, c_pad, static_cast<__bf16*>(out));
+        pack_rows_kernel<__bf16><<<dim3((unsigned)gx, B), 256, 0, s>>>(x, offsets, T, C, c_pad, static_cast<__bf16*>(out));
     else
-        pack_rows_kernel<float><<<dim3(gx, B), 256, 0, s>>>(x, offsets, T, C, c_pad, static_cast<float*>(out));
+        pack_rows_kernel<float><<<dim3((unsigned)gx, B), 256, 0, s>>>(x, offsets, T, C, c_pad, static_cast<float*>(out));
     return hipGetLastError();
 }
 
@@ -113,9 +114,9 @@ hipError_t launch_unpack_rows(const void* flat, bool in_bf16, int ld, int B, int
     int gx = (int)((per + 255) / 256);
     if (gx > 64) gx = 64;
     if (in_bf16)
-        unpack_rows_kernel<__bf16><<<dim3(gx, B), 256, 0, s>>>(static_cast<const __bf16*>(flat), ld, T_in, T_out, C, y);
+        unpack_rows_kernel<__bf16><<<dim3((unsigned)gx, B), 256, 0, s>>>(static_cast<const __bf16*>(flat), ld, T_in, T_out, C, y);
     else
-        unpack_rows_kernel<float><<<dim3(gx, B), 256, 0, s>>>(static_cast<const float*>(flat), ld, T_in, T_out, C, y);
+        unpack_rows_kernel<float><<<dim3((unsigned)gx, B), 256, 0, s>>>(static_cast<const float*>(flat), ld, T_in, T_out, C, y);
     return hipGetLastError();
 }
 

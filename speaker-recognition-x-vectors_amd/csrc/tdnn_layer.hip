@@ -485,7 +485,7 @@ hipError_t launch_tdnn(const TdnnArgs& a, TdnnVariant v, hipStream_t s) {
         case TdnnVariant::kF32: return launch_variant<false, false, true, false, false>(a, s);
         case TdnnVariant::kF32Pool: return launch_variant<false, true, false, false, false>(a, s);
         case TdnnVariant::kF32PoolStore: return launch_variant<false, true, true, false, false>(a, s);
-        case TdnnVariant::kF32FirstToBf16: return launch_variant<true, false, true, false, true>(a, s);
+        case TdnnVariant::kBf16First: return launch_variant<true, false, true, true, true>(a, s);
         case TdnnVariant::kBf16: return launch_variant<false, false, true, true, true>(a, s);
         case TdnnVariant::kBf16Pool: return launch_variant<false, true, false, true, false>(a, s);
         case TdnnVariant::kBf16ToF32: return launch_variant<false, false, true, true, false>(a, s);

@@ -71,7 +71,7 @@ namespace {
 
 struct Plan {
     int64_t total, m_pad, rows_alloc;
-    size_t xpad, actA, actB, act5, part, pooled, seg6, seg7, offs, bytes;
+    size_t xpad, x16, actA, actB, act5, part, pooled, seg6, seg7, offs, bytes;
     int64_t part_slots;
 };
 
@@ -85,6 +85,7 @@ Plan make_plan(const xvec_handle* h, int64_t total, int B) {
     const int nh = h->geo[0].n_pad, n5 = h->geo[4].n_pad;
     size_t o = 0;
     p.xpad = o;   o += align_up((size_t)p.rows_alloc * h->cin_pad * 4);
+    p.x16 = o;    o += align_up((size_t)p.rows_alloc * h->cin_pad * 2);
     p.actA = o;   o += align_up((size_t)p.rows_alloc * nh * 4);
     p.actB = o;   o += align_up((size_t)p.rows_alloc * nh * 4);
     p.act5 = o;   o += align_up((size_t)p.rows_alloc * n5 * 4);
@@ -150,7 +151,8 @@ struct StageTimer {
 // variants use the bf16 packing (64-element chunks) of the layer's weights.
 int run_tdnn(xvec_handle* h, int layer, TdnnVariant v, const void* X, int ldx, int64_t x_rows, void* Y,
              int64_t rows_out, const RowMap& out_map, float* part, hipStream_t s) {
-    const bool in16 = v == TdnnVariant::kBf16 || v == TdnnVariant::kBf16Pool || v == TdnnVariant::kBf16ToF32;
+    const bool in16 = v == TdnnVariant::kBf16 || v == TdnnVariant::kBf16Pool || v == TdnnVariant::kBf16ToF32 ||
+                      v == TdnnVariant::kBf16First;
     const TdnnGeom& g = in16 ? h->geo16[layer] : h->geo[layer];
     TdnnArgs a;
     memset(&a, 0, sizeof(a));
@@ -206,10 +208,10 @@ int forward_rows(xvec_handle* h, const float* x_rows, int ldx, const int64_t* of
     const int nh = h->geo[0].n_pad;
     int rc;
     const bool b16 = dtype == XVEC_BF16;
-    // layer 1 reads the caller's rows (guarded against the end of the buffer and the K tail); it is
-    // fp32 MFMA in both modes (fp32 MFCC input, 2.4 % of the FLOPs), bf16 mode rounds its output.
+    // layer 1 reads the caller's rows (guarded against the end of the buffer and the K tail); in
+    // bf16 mode the MFCC rows are first rounded to bf16 into the workspace.
     // Layer 5 carries the statistics-pooling epilogue: its [frames,1500] output stays on chip.
-    const TdnnVariant v1 = b16 ? TdnnVariant::kF32FirstToBf16 : TdnnVariant::kF32First;
+    const TdnnVariant v1 = b16 ? TdnnVariant::kBf16First : TdnnVariant::kF32First;
     const TdnnVariant vm = b16 ? TdnnVariant::kBf16 : TdnnVariant::kF32;
     const TdnnVariant v5 = b16 ? TdnnVariant::kBf16Pool : TdnnVariant::kF32Pool;
     // every layer's output is compact: utterance u keeps len_u - cum frames after `cum` frames of
@@ -222,6 +224,13 @@ int forward_rows(xvec_handle* h, const float* x_rows, int ldx, const int64_t* of
     void* bufs[2] = {actA, actB};
     const void* in = x_rows;
     int ld_in = ldx;
+    if (b16) {   // [total, ldx] fp32 -> bf16 (same row stride in elements)
+        if (p.total > 0x7fffffff) return fail(XVEC_ERR_ARG, "too many frames for one bf16 batch");
+        StageTimer t(h, T_PACK, s);
+        void* x16 = ws + p.x16;
+        HIP_TRY(launch_pack_rows(x_rows, nullptr, 1, (int)p.total, ldx, ldx, x16, true, s));
+        in = x16;
+    }
     for (int l = 0; l < XVEC_NUM_TDNN; ++l) {
         map.cum += h->geo[l].ctx_span;
         const int64_t rows_out = p.total - (int64_t)B * map.cum;
@@ -521,13 +530,13 @@ int xvec_tdnn_layer(xvec_handle* h, int layer, const float* x, int32_t B, int32_
     // bf16 mode: activations between layers are bf16 (layer 1 still reads fp32 MFCCs); the result is
     // widened back to fp32 for the caller
     const bool b16 = dtype == XVEC_BF16;
-    const bool in16 = b16 && layer > 0;
+    const bool in16 = b16;
     // stage the compact input into the layer's native row layout (stride = producer's n_pad)
     const int ldx = (layer == 0) ? h->cin_pad : h->geo[layer - 1].n_pad;
     void* xin = ws + (layer == 0 ? p.xpad : p.actA);
     HIP_TRY(launch_pack_rows(x, nullptr, B, T, g.src_cin, ldx, xin, in16, s));
     void* yflat = ws + (layer == 4 ? p.act5 : p.actB);
-    const TdnnVariant v = layer == 0 ? (b16 ? TdnnVariant::kF32FirstToBf16 : TdnnVariant::kF32First)
+    const TdnnVariant v = layer == 0 ? (b16 ? TdnnVariant::kBf16First : TdnnVariant::kF32First)
                                      : (b16 ? TdnnVariant::kBf16 : TdnnVariant::kF32);
     RowMap map;
     map.offsets = nullptr;

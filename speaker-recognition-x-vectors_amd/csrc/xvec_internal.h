@@ -86,7 +86,7 @@ enum class TdnnVariant {
     kF32,             // fp32 -> fp32
     kF32Pool,         // fp32 -> pooling partials only (layer 5)
     kF32PoolStore,    // fp32 -> fp32 + pooling partials
-    kF32FirstToBf16,  // layer 1 of the bf16 path: fp32 MFMA on the fp32 MFCCs, bf16 activations out
+    kBf16First,       // layer 1 of the bf16 path: guarded reads of the bf16-converted MFCC rows
     kBf16,            // bf16 -> bf16
     kBf16Pool,        // bf16 -> pooling partials only
     kBf16ToF32        // bf16 -> fp32 (per-layer test entry of layer 5)

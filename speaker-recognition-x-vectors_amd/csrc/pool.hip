@@ -5,7 +5,7 @@
 //                            the utterance as a shift (sums of (x-K), (x-K)^2 are well
 //                            conditioned since K is a sample of the same distribution).
 //  * pool_finalize_kernel -- merges the per-sub-tile (mean, M2) partials that the layer-5
-//                            epilogue (tdnn_f32.hip) writes, with Chan's pairwise update.
+//                            epilogue (tdnn_layer.hip) writes, with Chan's pairwise update.
 //
 // n == 1 gives NaN std exactly like torch.std (0/0); the caller rejects n < 1.
 #include "xvec_internal.h"

@@ -303,7 +303,7 @@ int stage_offsets(xvec_handle* h, const int64_t* offs_host, int B, int64_t* dev,
 int common_checks(xvec_handle* h, const void* x, int B, int mode, int dtype, const void* out, const void* ws) {
     if (!h) return fail(XVEC_ERR_ARG, "null handle");
     if (!x || !out || !ws) return fail(XVEC_ERR_ARG, "null tensor pointer");
-    if (B < 1) return fail(XVEC_ERR_ARG, "B must be >= 1 (got %d)", B);
+    if (B < 1 || B > 65535) return fail(XVEC_ERR_ARG, "B must be in [1, 65535] (got %d); split larger batches", B);
     if (mode != XVEC_MODE_LOGITS && mode != XVEC_MODE_XVEC6 && mode != XVEC_MODE_XVEC7)
         return fail(XVEC_ERR_ARG, "unknown mode %d", mode);
     if (dtype != XVEC_F32 && dtype != XVEC_BF16) return fail(XVEC_ERR_ARG, "unknown dtype %d", dtype);

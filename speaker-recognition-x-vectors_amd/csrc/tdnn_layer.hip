@@ -392,8 +392,26 @@ __global__ __launch_bounds__(256, 2) void tdnn_kernel(const TdnnArgs a) {
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
     const int j = lid % a.n_tiles;
     const int p = lid / a.n_tiles;
-    const int64_t g_begin = a.groups_total * (int64_t)p / a.blocks_per_col;
-    const int64_t g_end = a.groups_total * (int64_t)(p + 1) / a.blocks_per_col;
+    // Row range of this block.  G groups over P ranges: sizes differ by at most one.  With two
+    // blocks per CU the dispatcher places blocks b and b + grid/2 on the same CU (observed,
+    // profiles/diag/placement.hip; speed only): the ranges that get the extra group are chosen
+    // among the first-slot blocks first, so a CU's two blocks sum to the same work everywhere.
+    int64_t g_begin, g_end;
+    if (a.pair_period > 0) {
+        const int P = a.blocks_per_col, PQ = a.pair_period, hq = PQ >> 1;
+        const int64_t base = a.groups_total / P;
+        const int rem = (int)(a.groups_total % P);
+        const int rem1 = rem < (P >> 1) ? rem : (P >> 1), rem2 = rem - rem1;
+        const int xq = p / PQ, w = p % PQ;
+        const int nf = xq * hq + (w < hq ? w : hq);          // first-slot ranges before p
+        const int ns = xq * hq + (w > hq ? w - hq : 0);      // second-slot ranges before p
+        g_begin = base * p + (nf < rem1 ? nf : rem1) + (ns < rem2 ? ns : rem2);
+        const bool extra = (w < hq) ? (nf < rem1) : (ns < rem2);
+        g_end = g_begin + base + (extra ? 1 : 0);
+    } else {
+        g_begin = a.groups_total * (int64_t)p / a.blocks_per_col;
+        g_end = a.groups_total * (int64_t)(p + 1) / a.blocks_per_col;
+    }
     const int n0 = j * kBN;
     const int n_chunks = a.n_taps * a.cpt;
 

@@ -177,6 +177,11 @@ int run_tdnn(xvec_handle* h, int layer, TdnnVariant v, const void* X, int ldx, i
         if (per_col < 1) per_col = 1;
         if (per_col > a.groups_total) per_col = a.groups_total;
         a.blocks_per_col = (int)per_col;
+        // CU-pair-aware range sizes need the full 2-blocks-per-CU grid and whole XCD runs per half
+        const int nwg = a.blocks_per_col * a.n_tiles;
+        const bool ok = h->blocks_per_cu == 2 && nwg == 2 * h->num_cu && nwg % 16 == 0 &&
+                        (nwg / 8) % (2 * a.n_tiles) == 0 && !getenv("XVEC_NO_PAIR_BALANCE");
+        a.pair_period = ok ? (nwg / 8) / a.n_tiles : 0;
     }
     a.pool_part = part;
     a.out_map = out_map;

@@ -74,6 +74,7 @@ struct TdnnArgs {
     int n_tiles;              // 128-channel columns
     int blocks_per_col;       // persistent blocks per column; grid = n_tiles * blocks_per_col
     int64_t groups_total;     // 32-row groups of the flat frame axis (ceil(rows / 32))
+    int pair_period;          // >0: row ranges per XCD run; enables CU-pair-aware range sizes (see kernel)
     RowMap out_map;           // row layout of THIS layer's output
     int span;                 // frames this layer consumes (c[-1]-c[0]): input row = p + u(p)*span
     // fused statistics-pooling epilogue (layer 5)

@@ -127,6 +127,37 @@ int xvec_affine(xvec_handle* h, int which, const float* x, int32_t M, int relu, 
 int xvec_set_profiling(xvec_handle* h, int on);
 int xvec_get_timings(xvec_handle* h, float* ms, int* n);
 
+/* ---- next row N3: MFCC front end (the step in front of the path) ----------------------------
+ * python_speech_features.mfcc as the reference calls it in its DataLoader workers
+ * (reference dataset.py:128: mfcc(signal, 16000, numcep=24, nfilt=26, nfft=512)): pre-emphasis,
+ * rectangular 25 ms / 10 ms frames with a zero-padded tail, |rfft|^2/nfft, triangular mel
+ * filterbank, log, orthonormal DCT-II, lifter, c0 := log frame energy.  One kernel, one launch per
+ * batch of equal-length waveforms.  Parity is UNPINNED: the package is absent from the build image
+ * (oracle/mfcc_oracle.py restates its published algorithm). */
+typedef struct xvec_mfcc_plan xvec_mfcc_plan;
+typedef struct {
+    int32_t samplerate;    /* 16000 */
+    float winlen;          /* 0.025 s */
+    float winstep;         /* 0.01 s  */
+    int32_t numcep;        /* 24 in the reference (package default 13) */
+    int32_t nfilt;         /* 26 */
+    int32_t nfft;          /* 512; power of two in [64, 4096] */
+    float lowfreq;         /* 0 */
+    float highfreq;        /* 0 = samplerate/2 */
+    float preemph;         /* 0.97 */
+    int32_t ceplifter;     /* 22; 0 = no liftering */
+    int32_t append_energy; /* 1 */
+    int32_t device;
+} xvec_mfcc_cfg;
+int xvec_mfcc_create(const xvec_mfcc_cfg* cfg, xvec_mfcc_plan** out);
+void xvec_mfcc_destroy(xvec_mfcc_plan* plan);
+const char* xvec_mfcc_last_error(void);
+/* frames produced for n_samples samples: 1 + ceil((n - frame_len)/frame_step), 1 if n <= frame_len */
+int32_t xvec_mfcc_frames(const xvec_mfcc_plan* plan, int64_t n_samples);
+/* signal[B, n_samples] fp32 (device) -> out[B, frames, numcep] fp32 (device) */
+int xvec_mfcc(xvec_mfcc_plan* plan, const float* signal, int32_t B, int64_t n_samples, float* out,
+              xvec_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

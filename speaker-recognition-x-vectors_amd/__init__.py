@@ -6,7 +6,7 @@ hand-written gfx950 HIP kernels behind the C-ABI in include/xvec_hip.h.
 """
 from . import synth  # noqa: F401  (numpy only)
 
-__all__ = ["synth", "XVectorModel", "TdnnLayer", "get_time_context", "hip", "extract"]
+__all__ = ["synth", "XVectorModel", "TdnnLayer", "get_time_context", "MfccFrontEnd", "hip", "extract", "frontend"]
 
 
 def __getattr__(name):
@@ -14,7 +14,10 @@ def __getattr__(name):
     if name in ("XVectorModel", "TdnnLayer", "get_time_context"):
         from . import model
         return getattr(model, name)
-    if name in ("hip", "model", "extract"):
+    if name == "MfccFrontEnd":
+        from . import frontend
+        return frontend.MfccFrontEnd
+    if name in ("hip", "model", "extract", "frontend"):
         import importlib
         return importlib.import_module("." + name, __name__)
     raise AttributeError(name)

@@ -27,6 +27,13 @@ class XvecError(RuntimeError):
         self.code = code
 
 
+class MfccCfg(C.Structure):
+    _fields_ = [("samplerate", C.c_int32), ("winlen", C.c_float), ("winstep", C.c_float), ("numcep", C.c_int32),
+                ("nfilt", C.c_int32), ("nfft", C.c_int32), ("lowfreq", C.c_float), ("highfreq", C.c_float),
+                ("preemph", C.c_float), ("ceplifter", C.c_int32), ("append_energy", C.c_int32),
+                ("device", C.c_int32)]
+
+
 class Cfg(C.Structure):
     _fields_ = [("input_size", C.c_int32), ("hidden_size", C.c_int32), ("num_classes", C.c_int32),
                 ("x_vector_size", C.c_int32), ("batch_norm", C.c_int32), ("device", C.c_int32)]
@@ -58,6 +65,11 @@ _SIGS = {
     "xvec_affine": (C.c_int, [_vp, C.c_int, _f32p, _i32, C.c_int, _f32p, _vp]),
     "xvec_set_profiling": (C.c_int, [_vp, C.c_int]),
     "xvec_get_timings": (C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
+    "xvec_mfcc_create": (C.c_int, [C.POINTER(MfccCfg), C.POINTER(_vp)]),
+    "xvec_mfcc_destroy": (None, [_vp]),
+    "xvec_mfcc_last_error": (C.c_char_p, []),
+    "xvec_mfcc_frames": (C.c_int32, [_vp, _i64]),
+    "xvec_mfcc": (C.c_int, [_vp, _f32p, _i32, _i64, _f32p, _vp]),
 }
 EXPORTS = tuple(_SIGS)
 for _name, (_res, _args) in _SIGS.items():

@@ -1,0 +1,100 @@
+"""MFCC front end (next-row N3).  The package the reference uses (python_speech_features) is not
+installed here, so parity is UNPINNED: the oracle restates its published algorithm.  CPU tests
+check the restatement's internal identities; the GPU test checks the HIP kernel against it."""
+import numpy as np
+import pytest
+import torch
+
+import mfcc_oracle as mo
+
+
+def _speechlike(n, seed):
+    """Synthetic waveform with a speech-like dynamic range: decaying harmonics + noise floor,
+    amplitude-modulated, scaled like 16-bit PCM divided down (the reference min/max-normalises)."""
+    rng = np.random.default_rng(seed)
+    t = np.arange(n) / 16000.0
+    f0 = 110 + 40 * np.sin(2 * np.pi * 1.3 * t)
+    x = sum((0.6 ** k) * np.sin(2 * np.pi * np.cumsum(f0 * (k + 1)) / 16000.0) for k in range(12))
+    x = x * (0.55 + 0.45 * np.sin(2 * np.pi * 3.1 * t)) + 0.01 * rng.standard_normal(n)
+    return (x / np.abs(x).max()).astype(np.float32)
+
+
+def test_frame_count_matches_reference_shape():
+    # 3 s at 16 kHz -> 299 frames x 24 coefficients (reference main.py:113, dataset.py:204)
+    assert mo.num_frames(48000) == 299
+    f = mo.mfcc(_speechlike(48000, 0), 16000, numcep=24, nfilt=26, nfft=512)
+    assert f.shape == (299, 24) and f.dtype == np.float64 and np.isfinite(f).all()
+    assert mo.num_frames(400) == 1 and mo.num_frames(401) == 2 and mo.num_frames(100) == 1
+
+
+def test_oracle_internal_identities():
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal(2050)
+    # pre-emphasis definition
+    y = mo.preemphasis(x, 0.97)
+    assert y[0] == x[0] and np.allclose(y[1:], x[1:] - 0.97 * x[:-1])
+    # framing: 400-sample frames every 160 samples, zero padded tail
+    fr = mo.framesig(y, 400, 160)
+    assert fr.shape == (12, 400) and np.array_equal(fr[3], y[480:880])
+    assert np.array_equal(fr[-1, :290], y[1760:]) and not fr[-1, 290:].any()      # zero-padded tail
+    # power spectrum vs an explicit DFT of the zero-padded frame
+    k = np.arange(257)[:, None] * np.arange(512)[None, :]
+    dft = np.exp(-2j * np.pi * k / 512) @ np.concatenate([fr[2], np.zeros(112)])
+    assert np.allclose(mo.powspec(fr[2:3], 512)[0], np.abs(dft) ** 2 / 512, rtol=1e-10)
+    # filterbank: 26 triangles, peaks of 1 at the interior bin edges, neighbours sum to 1 between peaks
+    fb = mo.get_filterbanks(26, 512, 16000)
+    assert fb.shape == (26, 257) and fb.min() >= 0 and np.isclose(fb.max(), 1.0)
+    inner = fb[:, int(np.argmax(fb[0])):int(np.argmax(fb[-1])) + 1].sum(0)
+    assert np.allclose(inner, 1.0)
+    # orthonormal DCT-II equals scipy's
+    from scipy.fftpack import dct
+    z = rng.standard_normal((5, 26))
+    assert np.allclose(mo.dct2_ortho(z, 24), dct(z, type=2, axis=1, norm="ortho")[:, :24])
+    assert np.allclose(mo.lifter_coeffs(24)[:3], [1.0, 1 + 11 * np.sin(np.pi / 22), 1 + 11 * np.sin(2 * np.pi / 22)])
+
+
+def test_c0_is_log_energy():
+    x = _speechlike(8000, 3)
+    f = mo.mfcc(x, 16000, numcep=24, nfilt=26, nfft=512)
+    _, energy = mo.fbank(x.astype(np.float64), 16000, nfilt=26, nfft=512)
+    assert np.allclose(f[:, 0], np.log(energy))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_samples,B", [(48000, 3), (16000, 1), (401, 2), (250, 1), (47999, 2)])
+def test_mfcc_kernel_vs_oracle(n_samples, B):
+    import xvector_amd as xa
+    from conftest import assert_parity
+    fe = xa.MfccFrontEnd()
+    waves = np.stack([_speechlike(n_samples, 10 + i) * (0.2 + 0.4 * i) for i in range(B)])
+    got = fe(torch.from_numpy(waves).to("cuda:0")).cpu().numpy()
+    ref = np.stack([mo.mfcc(w, 16000, numcep=24, nfilt=26, nfft=512) for w in waves])
+    assert got.shape == ref.shape == (B, mo.num_frames(n_samples), 24)
+    # fp32 kernel vs float64 oracle: per-frame norm-wise 1e-4 (the model casts features to fp32
+    # anyway, reference main.py:137); element-wise 1e-3 of the mean magnitude (low-energy bands)
+    assert_parity(got, ref, 1e-4, "mfcc", elem_tol=1e-3)
+
+
+@pytest.mark.gpu
+def test_mfcc_feeds_the_extractor(gpu_model):
+    """waveforms -> MFCC -> x-vectors entirely on the GPU, shapes as in the reference (299 x 24)."""
+    import xvector_amd as xa
+    fe = xa.MfccFrontEnd()
+    waves = torch.from_numpy(np.stack([_speechlike(48000, 40 + i) for i in range(4)])).to("cuda:0")
+    feats = fe(waves)
+    assert feats.shape == (4, 299, 24)
+    xv = gpu_model.extract_x_vec(feats)
+    assert xv.shape == (4, 512) and torch.isfinite(xv).all()
+
+
+@pytest.mark.gpu
+def test_mfcc_silence_and_errors():
+    import xvector_amd as xa
+    fe = xa.MfccFrontEnd()
+    out = fe(torch.zeros(1, 1600, device="cuda:0")).cpu().numpy()
+    ref = mo.mfcc(np.zeros(1600), 16000, numcep=24, nfilt=26, nfft=512)      # zeros -> eps -> finite logs
+    assert np.isfinite(out).all() and np.allclose(out[0], ref, rtol=1e-4, atol=1e-3)
+    with pytest.raises(RuntimeError):
+        fe(torch.zeros(1, 1600))
+    with pytest.raises(Exception):
+        xa.MfccFrontEnd(nfft=500)

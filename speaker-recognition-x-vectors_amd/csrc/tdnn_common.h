@@ -22,12 +22,26 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // Fused statistics-pooling partial (main.py:59-63) of one 32-row group held in one accumulator:
 // for every utterance overlapping compact rows [row_g, row_g+32), the mean and M2 (sum of squared
 // deviations about that mean) of this lane's column over the utterance's frames in the group.
-__device__ __forceinline__ void pool_group(const TdnnArgs& a, const f32x16& v, int64_t row_g, int h, int col) {
+template <bool RAGGED>
+__device__ __forceinline__ void pool_group_impl(const TdnnArgs& a, const f32x16& v, int64_t row_g, int h, int col) {
     const int64_t grp = row_g >> 5;
-    for (int u = utt_of_row(a.out_map, row_g); u < a.out_map.n_utts; ++u) {
-        const int64_t off = row_off(a.out_map, u);
+    const RowMap& m = a.out_map;
+    const int64_t t_out = m.fixed_T - m.cum;
+    auto first_row = [&](int u) -> int64_t {
+        if (RAGGED) return m.offsets[u] - (int64_t)u * m.cum;
+        return (int64_t)u * t_out;
+    };
+    int u0;
+    if (RAGGED) {
+        u0 = utt_of_row(m, row_g);
+    } else {
+        const int64_t q = row_g / t_out;
+        u0 = (int)(q < m.n_utts - 1 ? q : m.n_utts - 1);
+    }
+    for (int u = u0; u < m.n_utts; ++u) {
+        const int64_t off = first_row(u);
         if (off >= row_g + 32) break;
-        const int64_t end = row_off(a.out_map, u + 1);
+        const int64_t end = first_row(u + 1);
         const int64_t lo_r = off > row_g ? off : row_g;
         const int64_t hi_r = end < row_g + 32 ? end : row_g + 32;
         if (hi_r <= lo_r) continue;
@@ -66,6 +80,12 @@ __device__ __forceinline__ void pool_group(const TdnnArgs& a, const f32x16& v, i
             part[a.ldy + col] = m2;
         }
     }
+}
+
+// (two code paths: see set_tile_rows in tdnn_layer.hip)
+__device__ __forceinline__ void pool_group(const TdnnArgs& a, const f32x16& v, int64_t row_g, int h, int col) {
+    if (a.out_map.offsets == nullptr) pool_group_impl<false>(a, v, row_g, h, col);
+    else pool_group_impl<true>(a, v, row_g, h, col);
 }
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {

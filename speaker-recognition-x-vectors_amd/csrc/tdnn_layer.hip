@@ -77,16 +77,47 @@ __device__ __forceinline__ float4 buf_load16(__amdgpu_buffer_rsrc_t rsrc, int vo
 
 // per-thread input offsets of the four staging rows (r0 + 32j) of the tile the stream is in: the
 // compact output row p of utterance u reads input rows p + u*span (+ tap shift).  The utterance of
-// the tile's first row is tracked incrementally (cx.u_tile / cx.off_next: tiles only move forward),
-// each row then walks at most a few utterance boundaries -- no division per tile.
-__device__ __forceinline__ int rebase_rows(const TdnnArgs& a, const Ctx& cx, int64_t p) {
+// the tile's first row is tracked incrementally (cx.u_tile / cx.off_next: tiles only move
+// forward); the few utterance boundaries inside the tile are walked with block-uniform values
+// (scalar loads of the offsets for ragged batches) and each lane just counts how many of them its
+// rows have passed -- no division, and no vector-memory load whose wait would drain the
+// staging loads in flight.
+// The fixed-length and the ragged case are two separate code paths on purpose: sharing one loop made
+// hipcc put the ragged path's s_waitcnt vmcnt(0) (for the offsets load) on the fixed path too,
+// draining the 16 staging loads in flight at every tile change.
+template <bool RAGGED>
+__device__ __forceinline__ void set_tile_rows_impl(const TdnnArgs& a, Ctx& cx) {
+    const int n_last = a.out_map.n_utts - 1;
+    const int64_t t_out = a.out_map.fixed_T - a.out_map.cum;          // fixed-length: rows per utterance
+    auto next_off = [&](int u) -> int64_t {                            // first row of utterance u+1
+        if (RAGGED) return a.out_map.offsets[u + 1] - (int64_t)(u + 1) * a.out_map.cum;
+        return (int64_t)(u + 1) * t_out;
+    };
+    while (cx.m0 >= cx.off_next && cx.u_tile < n_last) {
+        cx.u_tile = __builtin_amdgcn_readfirstlane(cx.u_tile + 1);
+        cx.off_next = next_off(cx.u_tile);
+    }
+    const int64_t p = cx.m0 + cx.r0;
+    int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
     int u = cx.u_tile;
     int64_t nxt = cx.off_next;
-    while (p >= nxt && u < a.out_map.n_utts - 1) {
-        ++u;
-        nxt = row_off(a.out_map, u + 1);
+    while (nxt < cx.m0 + 128 && u < n_last) {       // block-uniform walk over the boundaries in the tile
+        c0 += (p >= nxt) ? 1 : 0;
+        c1 += (p + 32 >= nxt) ? 1 : 0;
+        c2 += (p + 64 >= nxt) ? 1 : 0;
+        c3 += (p + 96 >= nxt) ? 1 : 0;
+        u = __builtin_amdgcn_readfirstlane(u + 1);
+        nxt = next_off(u);
     }
-    return u * a.span;
+    const int rb = a.ldx * cx.es;
+    cx.ur0 = (cx.u_tile + c0) * a.span;
+    cx.ur1 = (cx.u_tile + c1) * a.span;
+    cx.ur2 = (cx.u_tile + c2) * a.span;
+    cx.ur3 = (cx.u_tile + c3) * a.span;
+    cx.xo0 = cx.x_base + cx.ur0 * rb;
+    cx.xo1 = cx.x_base + cx.ur1 * rb;
+    cx.xo2 = cx.x_base + cx.ur2 * rb;
+    cx.xo3 = cx.x_base + cx.ur3 * rb;
 }
 
 __device__ __forceinline__ void set_tile_rows(const TdnnArgs& a, Ctx& cx) {
@@ -95,20 +126,8 @@ __device__ __forceinline__ void set_tile_rows(const TdnnArgs& a, Ctx& cx) {
         cx.xo0 = cx.xo1 = cx.xo2 = cx.xo3 = cx.x_base;
         return;
     }
-    while (cx.m0 >= cx.off_next && cx.u_tile < a.out_map.n_utts - 1) {   // block-uniform
-        ++cx.u_tile;
-        cx.off_next = row_off(a.out_map, cx.u_tile + 1);
-    }
-    const int64_t p = cx.m0 + cx.r0;
-    const int rb = a.ldx * cx.es;
-    cx.ur0 = rebase_rows(a, cx, p);
-    cx.ur1 = rebase_rows(a, cx, p + 32);
-    cx.ur2 = rebase_rows(a, cx, p + 64);
-    cx.ur3 = rebase_rows(a, cx, p + 96);
-    cx.xo0 = cx.x_base + cx.ur0 * rb;
-    cx.xo1 = cx.x_base + cx.ur1 * rb;
-    cx.xo2 = cx.x_base + cx.ur2 * rb;
-    cx.xo3 = cx.x_base + cx.ur3 * rb;
+    if (a.out_map.offsets == nullptr) set_tile_rows_impl<false>(a, cx);
+    else set_tile_rows_impl<true>(a, cx);
 }
 
 // Step the load stream to the next K-chunk.  The stream is continuous over the block's tiles:
@@ -370,7 +389,7 @@ __global__ __launch_bounds__(256, 2) void tdnn_kernel(const TdnnArgs a) {
     cx.x_base = ln.r0 * a.ldx * ES + ln.c * 16;
     cx.w_toff = ln.r0 * a.k_pad * ES + ln.c * 16;
     cx.r0 = ln.r0;
-    cx.u_tile = utt_of_row(a.out_map, cx.m0);
+    cx.u_tile = __builtin_amdgcn_readfirstlane(utt_of_row(a.out_map, cx.m0));
     cx.off_next = row_off(a.out_map, cx.u_tile + 1);
     set_tile_rows(a, cx);
     cx.tap = 0;

@@ -296,34 +296,73 @@ __device__ __forceinline__ void process_tile(const TdnnArgs& a, float* smem, Ctx
 #pragma unroll
     for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; acc2[e] = 0.f; acc3[e] = 0.f; }
 
+#ifdef XVEC_DIAG
+    SB();
+    const unsigned long long dt0 = __builtin_amdgcn_s_memtime();
+    SB();
+#endif
     // ---- K chunks, two per trip (LDS buffer 0 then 1); n_chunks is even
     for (int it = 0; it < n_chunks; it += 2) {
         XV_CHUNK(0, 1)
         XV_CHUNK(1, 0)
     }
+#ifdef XVEC_DIAG
+    SB();
+    const unsigned long long dt1 = __builtin_amdgcn_s_memtime();
+    SB();
+#endif
 
     const int64_t m0 = g0 * 32;
     // ---- epilogue: bias + ReLU + folded BatchNorm (tdnn_layer.py:30-39)
     // accumulator element e of lane (r, h): row = (e&3) + 8*(e>>2) + 4*h, col = r
     const int col = ln.col;
     const float bi = ln.bias, sc = ln.scale, sh = ln.shift;
+    // Two phases per row group: (1) all 16 values finished IN PLACE in the accumulator registers,
+    // (2) 16 stores issued back to back from those 16 distinct registers, addressed by a per-tile
+    // buffer descriptor + one per-lane offset + a scalar row offset.  (Computing each value into a
+    // shared temporary right before its store made every store wait for the previous one to have
+    // read that register, and chained 64-bit address adds: ~23k cycles per tile in layer 2.)
+    const int esz = OUTBF ? 2 : 4;
+    __amdgpu_buffer_rsrc_t yrsrc;
+    int y_voff = 0;
+    if (STORE) {
+        yrsrc = make_rsrc(static_cast<char*>(a.Y) + (m0 * (int64_t)a.ldy + n0) * esz);
+        y_voff = (4 * h * a.ldy + (col - n0)) * esz;
+    }
 #define XV_EPI(i_)                                                                                        \
     if constexpr (G > i_) {                                                                               \
-        _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                                  \
-            float v = acc##i_[e] + bi;                                                                    \
-            v = fmaxf(v, 0.f);                                                                            \
-            v = fmaf(v, sc, sh);                                                                          \
-            acc##i_[e] = v;                                                                               \
-            if (STORE) {                                                                                  \
-                const int64_t row = m0 + i_ * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;                        \
-                if constexpr (OUTBF) static_cast<__bf16*>(a.Y)[row * a.ldy + col] = (__bf16)v;            \
-                else static_cast<float*>(a.Y)[row * a.ldy + col] = v;                                     \
+        _Pragma("unroll") for (int e = 0; e < 16; ++e)                                                    \
+            acc##i_[e] = fmaf(fmaxf(acc##i_[e] + bi, 0.f), sc, sh);                                       \
+        asm volatile("" : "+v"(acc##i_));                                                                 \
+        if (STORE) {                                                                                      \
+            _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                              \
+                const int soff = (i_ * 32 + (e & 3) + 8 * (e >> 2)) * a.ldy * esz;                        \
+                if constexpr (OUTBF) {                                                                    \
+                    const __bf16 hv = (__bf16)acc##i_[e];                                                 \
+                    __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, hv), yrsrc,  \
+                                                          y_voff, soff, 0);                               \
+                } else {                                                                                  \
+                    const float fv = acc##i_[e]; /* scalar copy: bit_cast of a vector ELEMENT is miscompiled */ \
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(fv), yrsrc, y_voff, soff, 0);   \
+                }                                                                                         \
             }                                                                                             \
         }                                                                                                 \
-        if (POOL) pool_group(a, acc##i_, m0 + i_ * 32, h, col);                                        \
+        if (POOL) pool_group(a, acc##i_, m0 + i_ * 32, h, col);                                           \
     }
     XV_EPI(0) XV_EPI(1) XV_EPI(2) XV_EPI(3)
 #undef XV_EPI
+#ifdef XVEC_DIAG
+    SB();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const unsigned long long dt2 = __builtin_amdgcn_s_memtime();
+    SB();
+    if (threadIdx.x == 0 && blockIdx.x < 8192) {
+        unsigned long long* d = g_diag + blockIdx.x * 8;
+        d[3] += dt1 - dt0;     // K loop
+        d[4] += dt2 - dt1;     // epilogue (issue side; stores still in flight)
+        d[5] += 1;             // tiles
+    }
+#endif
 }
 
 template <bool GUARD, bool POOL, bool STORE, bool INBF, bool OUTBF>
@@ -331,6 +370,7 @@ __global__ __launch_bounds__(256, 2) void tdnn_kernel(const TdnnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
 #ifdef XVEC_DIAG
     const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
+    if (threadIdx.x == 0 && blockIdx.x < 8192) { g_diag[blockIdx.x * 8 + 3] = 0; g_diag[blockIdx.x * 8 + 4] = 0; g_diag[blockIdx.x * 8 + 5] = 0; }
 #endif
     // logical id -> (row range p, channel column j); the n_tiles columns of one range are
     // consecutive ids on one XCD

@@ -54,8 +54,28 @@ hipError_t launch_pack_tdnn(const float* W, const float* bias, const float* g, c
     return hipGetLastError();
 }
 
-hipError_t launch_pack_tdnn_bf16(const float* W, const TdnnGeom& geo, void* Wp16, hipStream_t s) {
-    pack_tdnn_weight_kernel<__bf16><<<1024, 256, 0, s>>>(W, geo, static_cast<__bf16*>(Wp16));
+// Same matrix in bf16, fragment-major for v_mfma_f32_32x32x16_bf16: the 64 lanes' B operands of one
+// (32-channel column tile, 16-wide k-step) are one contiguous KiB, so a wave fetches them with a
+// single coalesced 16-byte-per-lane load and the weights never pass through LDS.
+__global__ void pack_tdnn_weight_frag_kernel(const float* __restrict__ W, TdnnGeom g, __bf16* __restrict__ Wf) {
+    const int64_t total = (int64_t)g.n_pad * g.k_pad;
+    const int ksteps = g.k_pad / 16;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t blk = i >> 9;
+        const int within = (int)(i & 511), lane = within >> 3, j = within & 7;
+        const int ct = (int)(blk / ksteps), ks = (int)(blk % ksteps);
+        const int n = ct * 32 + (lane & 31), kd = ks * 16 + 8 * (lane >> 5) + j;
+        const int tap = kd / g.tap_stride_src, c = kd % g.tap_stride_src;
+        float v = 0.f;
+        if (n < g.cout && tap < g.src_taps && c < g.src_cin)
+            v = W[(int64_t)n * (g.src_taps * g.src_cin) + tap * g.src_cin + c];
+        Wf[i] = (__bf16)v;
+    }
+}
+
+hipError_t launch_pack_tdnn_bf16(const float* W, const TdnnGeom& geo, void* Wf16, hipStream_t s) {
+    pack_tdnn_weight_frag_kernel<<<1024, 256, 0, s>>>(W, geo, static_cast<__bf16*>(Wf16));
     return hipGetLastError();
 }
 

@@ -58,6 +58,8 @@ struct Ctx {
     int ur0, ur1, ur2, ur3;   // u(row r0+32j of the tile)*span: rows to add to re-base into the input layout
     int xo0, xo1, xo2, xo3;   // x_base + ur_j*ldx*ES
     int w_toff;          // r0*k_pad*ES + c*16 bytes
+    __amdgpu_buffer_rsrc_t wfrsrc;   // bf16: fragment-major weights of this wave's 32-channel column tile
+    int wf_voff;         // lane*16
     int r0;
     int u_tile;          // utterance holding row m0 (block-uniform), and the first row of the next one
     int64_t off_next;
@@ -167,12 +169,14 @@ __device__ __forceinline__ void advance(const TdnnArgs& a, Ctx& cx, int n_chunks
 // fragment reads (LDS -> VGPR) of k-group q_ into fragment set f_ from buffer base S_
 #define XV_FRG_A(i_, q_, f_, S_) \
     if constexpr (G > i_) { rg.fa##i_##_##f_ = *reinterpret_cast<const float4*>((S_) + a_rd + i_ * 32 * kBK + XV_KO(q_)); }
-#define XV_FRG_B(q_, f_, S_) rg.fb_##f_ = *reinterpret_cast<const float4*>((S_) + b_rd + XV_KO(q_));
+// fp32: B fragment from the LDS image.  bf16: B fragments never touch LDS (see XV_GLB below).
+#define XV_FRG_B(q_, f_, S_) \
+    if constexpr (!INBF) { rg.fb_##f_ = *reinterpret_cast<const float4*>((S_) + b_rd + XV_KO(q_)); }
 // LDS stores of staging set n_ into LDS buffer n_
 #define XV_LST_A(i_, n_) \
     if constexpr (G > i_) { *reinterpret_cast<float4*>(smem + n_ * kStageFloats + st_off + i_ * 32 * kBK) = rg.sA##i_##_##n_; }
 #define XV_LST_B(j_, n_) \
-    *reinterpret_cast<float4*>(smem + n_ * kStageFloats + st_off + kBM * kBK + j_ * 32 * kBK) = rg.sB##j_##_##n_;
+    if constexpr (!INBF) { *reinterpret_cast<float4*>(smem + n_ * kStageFloats + st_off + kBM * kBK + j_ * 32 * kBK) = rg.sB##j_##_##n_; }
 // global loads of the chunk cx points at into staging set n_
 #define XV_GLD_A(i_, n_)                                                                                  \
     if constexpr (G > i_) {                                                                               \
@@ -188,8 +192,18 @@ __device__ __forceinline__ void advance(const TdnnArgs& a, Ctx& cx, int n_chunks
         }                                                                                                 \
     }
 #define XV_GLD_B(j_, n_)                                                                                  \
-    {                                                                                                     \
+    if constexpr (!INBF) {                                                                                \
         rg.sB##j_##_##n_ = buf_load16(cx.wrsrc, cx.w_toff, (32 * j_ * a.k_pad + cx.itl * BKE) * ES);         \
+    }
+// bf16: the weights are packed fragment-major at load time (pack.hip): for a 32-channel column
+// tile and a 16-wide k-step, the 64 lanes' 16-byte MFMA B operands are one contiguous KiB.  Each
+// wave reads its own B fragments straight into registers, one coalesced buffer load per k-step;
+// LDS carries only the activations.  Fragment q (k-step q of a 64-wide chunk) of chunk c_ -> set s_.
+#define XV_GLB(q_, s_, c_)                                                                                \
+    if constexpr (INBF) {                                                                                 \
+        int cw_ = (c_);                                                                                   \
+        if (cw_ >= n_chunks) cw_ -= n_chunks;                                                             \
+        rg.gb##q_##_##s_ = buf_load16(cx.wfrsrc, cx.wf_voff, (4 * cw_ + q_) * 1024);                      \
     }
 #define XV_GLD_ALL(n_) XV_GLD_A(0, n_) XV_GLD_A(1, n_) XV_GLD_A(2, n_) XV_GLD_A(3, n_) \
                        XV_GLD_B(0, n_) XV_GLD_B(1, n_) XV_GLD_B(2, n_) XV_GLD_B(3, n_)
@@ -204,18 +218,18 @@ __device__ __forceinline__ void advance(const TdnnArgs& a, Ctx& cx, int n_chunks
     slot_                                                                                                 \
     SB();
 // bf16: one MFMA per row group consumes the whole 16-byte fragment (k-step of 16)
-#define XV_MFB(i_, f_)                                                                                    \
+#define XV_MFB(i_, f_, q_, P_)                                                                            \
     if constexpr (G > i_) {                                                                               \
         acc##i_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, rg.fa##i_##_##f_),   \
-                                                          __builtin_bit_cast(bf16x8, rg.fb_##f_), acc##i_, 0, 0, 0); \
+                                                          __builtin_bit_cast(bf16x8, rg.gb##q_##_##P_), acc##i_, 0, 0, 0); \
     }                                                                                                     \
     SB();
 // one k-group with 16 slots.  fp32: 4 k components x 4 row groups = 16 MFMAs, one slot behind each;
 // bf16: 4 MFMAs (k-step 16), four slots behind each
-#define XV_KG(f_, s0, s1, s2, s3, s4, s5, s6, s7, s8, s9, s10, s11, s12, s13, s14, s15)                   \
+#define XV_KG(q_, P_, f_, s0, s1, s2, s3, s4, s5, s6, s7, s8, s9, s10, s11, s12, s13, s14, s15)           \
     if constexpr (INBF) {                                                                                 \
-        XV_MFB(0, f_) s0 s1 s2 s3 SB(); XV_MFB(1, f_) s4 s5 s6 s7 SB();                                   \
-        XV_MFB(2, f_) s8 s9 s10 s11 SB(); XV_MFB(3, f_) s12 s13 s14 s15 SB();                             \
+        XV_MFB(0, f_, q_, P_) s0 s1 s2 s3 SB(); XV_MFB(1, f_, q_, P_) s4 s5 s6 s7 SB();                   \
+        XV_MFB(2, f_, q_, P_) s8 s9 s10 s11 SB(); XV_MFB(3, f_, q_, P_) s12 s13 s14 s15 SB();             \
     } else {                                                                                              \
         XV_MF(0, x, f_, s0) XV_MF(1, x, f_, s1) XV_MF(2, x, f_, s2) XV_MF(3, x, f_, s3)                   \
         XV_MF(0, y, f_, s4) XV_MF(1, y, f_, s5) XV_MF(2, y, f_, s6) XV_MF(3, y, f_, s7)                   \
@@ -226,26 +240,26 @@ __device__ __forceinline__ void advance(const TdnnArgs& a, Ctx& cx, int n_chunks
 // One K-chunk held in LDS buffer P_; N_ = the other buffer = the staging set holding chunk it+1.
 // Branch-free: the last chunk of a tile also stores/loads/reads ahead (clamped to the last
 // chunk, results unused) -- n_chunks is even, so the two-chunk loop body needs no tail variants.
-#define XV_CHUNK(P_, N_)                                                                                  \
+#define XV_CHUNK(P_, N_, IT_)                                                                             \
     {                                                                                                     \
         const float* S = smem + P_ * kStageFloats;                                                        \
         const float* Sn = smem + N_ * kStageFloats;                                                       \
-        XV_KG(0, XV_FRG_A(0, 1, 1, S), XV_FRG_A(1, 1, 1, S), XV_FRG_A(2, 1, 1, S), XV_FRG_A(3, 1, 1, S),  \
-              XV_FRG_B(1, 1, S),                                                                          \
+        XV_KG(0, P_, 0, XV_FRG_A(0, 1, 1, S), XV_FRG_A(1, 1, 1, S), XV_FRG_A(2, 1, 1, S),                 \
+              XV_FRG_A(3, 1, 1, S), XV_FRG_B(1, 1, S),                                                    \
               XV_LST_A(0, N_), XV_LST_A(1, N_), XV_LST_A(2, N_), XV_LST_A(3, N_),                         \
               XV_LST_B(0, N_), XV_LST_B(1, N_), XV_LST_B(2, N_), XV_LST_B(3, N_),                         \
-              XV_NOP, XV_NOP, advance(a, cx, n_chunks);)                                                  \
-        XV_KG(1, XV_FRG_A(0, 2, 0, S), XV_FRG_A(1, 2, 0, S), XV_FRG_A(2, 2, 0, S), XV_FRG_A(3, 2, 0, S),  \
-              XV_FRG_B(2, 0, S),                                                                          \
+              XV_GLB(3, N_, (IT_) + 1), XV_NOP, advance(a, cx, n_chunks);)                                \
+        XV_KG(1, P_, 1, XV_FRG_A(0, 2, 0, S), XV_FRG_A(1, 2, 0, S), XV_FRG_A(2, 2, 0, S),                 \
+              XV_FRG_A(3, 2, 0, S), XV_FRG_B(2, 0, S),                                                    \
               XV_GLD_A(0, N_), XV_GLD_A(1, N_), XV_GLD_A(2, N_), XV_GLD_A(3, N_),                         \
               XV_GLD_B(0, N_), XV_GLD_B(1, N_), XV_GLD_B(2, N_), XV_GLD_B(3, N_),                         \
-              XV_NOP, XV_NOP, XV_NOP)                                                                     \
-        XV_KG(0, XV_FRG_A(0, 3, 1, S), XV_FRG_A(1, 3, 1, S), XV_FRG_A(2, 3, 1, S), XV_FRG_A(3, 3, 1, S),  \
-              XV_FRG_B(3, 1, S), XV_NOP, XV_NOP, XV_NOP, XV_NOP, XV_NOP, XV_NOP, XV_NOP, XV_NOP, XV_NOP,  \
-              XV_NOP, XV_NOP)                                                                             \
+              XV_GLB(0, P_, (IT_) + 2), XV_NOP, XV_NOP)                                                   \
+        XV_KG(2, P_, 0, XV_FRG_A(0, 3, 1, S), XV_FRG_A(1, 3, 1, S), XV_FRG_A(2, 3, 1, S),                 \
+              XV_FRG_A(3, 3, 1, S), XV_FRG_B(3, 1, S), XV_GLB(1, P_, (IT_) + 2), XV_NOP, XV_NOP, XV_NOP,  \
+              XV_NOP, XV_NOP, XV_NOP, XV_NOP, XV_NOP, XV_NOP, XV_NOP)                                     \
         __syncthreads(); /* chunk it+1 complete in LDS; chunk it's buffer is free */                     \
-        XV_KG(1, XV_FRG_A(0, 0, 0, Sn), XV_FRG_A(1, 0, 0, Sn), XV_FRG_A(2, 0, 0, Sn),                     \
-              XV_FRG_A(3, 0, 0, Sn), XV_FRG_B(0, 0, Sn), XV_NOP, XV_NOP, XV_NOP,                          \
+        XV_KG(3, P_, 1, XV_FRG_A(0, 0, 0, Sn), XV_FRG_A(1, 0, 0, Sn), XV_FRG_A(2, 0, 0, Sn),              \
+              XV_FRG_A(3, 0, 0, Sn), XV_FRG_B(0, 0, Sn), XV_GLB(2, P_, (IT_) + 2), XV_NOP, XV_NOP,        \
               XV_NOP, XV_NOP, XV_NOP, XV_NOP, XV_NOP, XV_NOP, XV_NOP, XV_NOP)                             \
     }
 
@@ -256,6 +270,7 @@ struct Regs {
     float4 sA0_0, sA1_0, sA2_0, sA3_0, sB0_0, sB1_0, sB2_0, sB3_0;
     float4 sA0_1, sA1_1, sA2_1, sA3_1, sB0_1, sB1_1, sB2_1, sB3_1;
     float4 fa0_0, fa1_0, fa2_0, fa3_0, fb_0, fa0_1, fa1_1, fa2_1, fa3_1, fb_1;
+    float4 gb0_0, gb1_0, gb2_0, gb3_0, gb0_1, gb1_1, gb2_1, gb3_1;   // bf16: B fragments of two chunks, from global
 };
 
 struct Lane {
@@ -282,6 +297,8 @@ __device__ __forceinline__ void block_prologue(const TdnnArgs& a, float* smem, C
     __syncthreads();
     XV_FRG_A(0, 0, 0, smem) XV_FRG_A(1, 0, 0, smem) XV_FRG_A(2, 0, 0, smem) XV_FRG_A(3, 0, 0, smem)
     XV_FRG_B(0, 0, smem)
+    XV_GLB(0, 0, 0) XV_GLB(1, 0, 0) XV_GLB(2, 0, 0) XV_GLB(3, 0, 0)
+    XV_GLB(0, 1, 1) XV_GLB(1, 1, 1) XV_GLB(2, 1, 1) XV_GLB(3, 1, 1)
     SB();
 }
 
@@ -303,8 +320,8 @@ __device__ __forceinline__ void process_tile(const TdnnArgs& a, float* smem, Ctx
 #endif
     // ---- K chunks, two per trip (LDS buffer 0 then 1); n_chunks is even
     for (int it = 0; it < n_chunks; it += 2) {
-        XV_CHUNK(0, 1)
-        XV_CHUNK(1, 0)
+        XV_CHUNK(0, 1, it)
+        XV_CHUNK(1, 0, it + 1)
     }
 #ifdef XVEC_DIAG
     SB();
@@ -429,6 +446,11 @@ __global__ __launch_bounds__(256, 2) void tdnn_kernel(const TdnnArgs a) {
     cx.x_base = ln.r0 * a.ldx * ES + ln.c * 16;
     cx.w_toff = ln.r0 * a.k_pad * ES + ln.c * 16;
     cx.r0 = ln.r0;
+    if (INBF) {   // 1 KiB per (column tile of 32 channels, k-step of 16)
+        const int64_t ct = n0 / 32 + wave;
+        cx.wfrsrc = make_rsrc(static_cast<const char*>(a.Wf) + ct * (int64_t)(a.k_pad / 16) * 1024);
+        cx.wf_voff = lane * 16;
+    }
     cx.u_tile = __builtin_amdgcn_readfirstlane(utt_of_row(a.out_map, cx.m0));
     cx.off_next = row_off(a.out_map, cx.u_tile + 1);
     set_tile_rows(a, cx);

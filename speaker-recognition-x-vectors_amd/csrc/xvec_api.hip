@@ -46,7 +46,7 @@ struct xvec_handle {
     int cin_pad;                       // input_size rounded up to 4 (row stride of layer-1 input)
     TdnnGeom geo[XVEC_NUM_TDNN];
     TdnnGeom geo16[XVEC_NUM_TDNN];     // bf16 packing of layers 2-5: 64-element chunks (layer 1 stays fp32)
-    void* Wp16[XVEC_NUM_TDNN];
+    void* Wp16[XVEC_NUM_TDNN];         // bf16, fragment-major
     float* Wp[XVEC_NUM_TDNN];
     float* vec[XVEC_NUM_TDNN];         // bias | scale | shift, n_pad each
     bool tdnn_loaded[XVEC_NUM_TDNN];
@@ -157,7 +157,8 @@ int run_tdnn(xvec_handle* h, int layer, TdnnVariant v, const void* X, int ldx, i
     TdnnArgs a;
     memset(&a, 0, sizeof(a));
     a.X = X;
-    a.W = in16 ? h->Wp16[layer] : static_cast<const void*>(h->Wp[layer]);
+    a.W = h->Wp[layer];
+    a.Wf = h->Wp16[layer];
     a.bias = h->vec[layer];
     a.scale = h->vec[layer] + g.n_pad;
     a.shift = h->vec[layer] + 2 * g.n_pad;

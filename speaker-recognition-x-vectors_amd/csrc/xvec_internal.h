@@ -62,7 +62,8 @@ struct TdnnGeom {
 
 struct TdnnArgs {
     const void* X;      // [rows][ldx]  fp32 or bf16
-    const void* W;      // packed [n_pad][k_pad]  fp32 or bf16
+    const void* W;      // fp32: packed row-major [n_pad][k_pad]
+    const void* Wf;     // bf16: fragment-major packing of the same matrix (see pack.hip)
     const float* bias;  // [n_pad]
     const float* scale; // [n_pad]  folded BatchNorm: y = relu(v)*scale + shift
     const float* shift; // [n_pad]
@@ -118,7 +119,9 @@ hipError_t launch_affine_f32(const float* x, const float* W, const float* b, flo
 hipError_t launch_pack_tdnn(const float* W, const float* bias, const float* g, const float* be,
                             const float* mu, const float* var, float eps, const TdnnGeom& geo,
                             float* Wp, float* bias_p, float* scale_p, float* shift_p, hipStream_t s);
-hipError_t launch_pack_tdnn_bf16(const float* W, const TdnnGeom& geo, void* Wp16, hipStream_t s);
+// bf16 fragment-major packing: block (column tile ct of 32 channels, k-step ks of 16) = 64 lanes x 8 bf16,
+// lane (r,h) element j = W[32*ct + r][16*ks + 8*h + j]
+hipError_t launch_pack_tdnn_bf16(const float* W, const TdnnGeom& geo, void* Wf16, hipStream_t s);
 // x[B,T,C] (+lengths) -> packed rows [sum len, c_pad] (fp32 or bf16); offsets on device
 hipError_t launch_pack_rows(const float* x, const int64_t* offsets, int B, int T, int C, int c_pad,
                             void* out, bool out_bf16, hipStream_t s);

@@ -4,14 +4,23 @@
 
 namespace xvec {
 
+// The kernel walks K in 128-byte chunks with the taps innermost (chunk kc of tap 0, of tap 1, ...,
+// then chunk kc+1), so the packed K axis is stored in that order:
+//   packed k = (kc*n_taps + tap)*chunk_k + w   <->   tap-major k = tap*tap_stride + kc*chunk_k + w.
+__device__ __forceinline__ int tap_major_k(const TdnnGeom& g, int kd) {
+    if (g.n_taps == 1) return kd;
+    const int it = kd / g.chunk_k, w = kd % g.chunk_k;
+    return (it % g.n_taps) * g.tap_stride_src + (it / g.n_taps) * g.chunk_k + w;
+}
+
 // PyTorch TdnnLayer.linear.weight[out, taps*cin] (column = tap*cin + c, tdnn_layer.py:19,29)
-//   -> Wp[n_pad][k_pad], k = tap*tap_stride + c, zero padded.
+//   -> Wp[n_pad][k_pad], zero padded, K in the order above.
 template <typename TO>
 __global__ void pack_tdnn_weight_kernel(const float* __restrict__ W, TdnnGeom g, TO* __restrict__ Wp) {
     const int64_t total = (int64_t)g.n_pad * g.k_pad;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
          i += (int64_t)gridDim.x * blockDim.x) {
-        const int n = (int)(i / g.k_pad), kd = (int)(i % g.k_pad);
+        const int n = (int)(i / g.k_pad), kd = tap_major_k(g, (int)(i % g.k_pad));
         const int tap = kd / g.tap_stride_src, c = kd % g.tap_stride_src;
         float v = 0.f;
         if (n < g.cout && tap < g.src_taps && c < g.src_cin)
@@ -65,7 +74,7 @@ __global__ void pack_tdnn_weight_frag_kernel(const float* __restrict__ W, TdnnGe
         const int64_t blk = i >> 9;
         const int within = (int)(i & 511), lane = within >> 3, j = within & 7;
         const int ct = (int)(blk / ksteps), ks = (int)(blk % ksteps);
-        const int n = ct * 32 + (lane & 31), kd = ks * 16 + 8 * (lane >> 5) + j;
+        const int n = ct * 32 + (lane & 31), kd = tap_major_k(g, ks * 16 + 8 * (lane >> 5) + j);
         const int tap = kd / g.tap_stride_src, c = kd % g.tap_stride_src;
         float v = 0.f;
         if (n < g.cout && tap < g.src_taps && c < g.src_cin)

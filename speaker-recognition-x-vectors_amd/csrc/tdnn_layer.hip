@@ -139,10 +139,12 @@ __device__ __forceinline__ void set_tile_rows(const TdnnArgs& a, Ctx& cx) {
 // (the look-ahead of the final chunks re-reads that chunk; the data is never used).
 __device__ __forceinline__ void advance(const TdnnArgs& a, Ctx& cx, int n_chunks) {
     if (cx.itl + 1 < n_chunks) {
+        // taps innermost: consecutive chunks re-read the same 128-byte slab of activation rows,
+        // shifted by the dilation, while it is still in L2 (the packed weights follow this order)
         ++cx.itl;
-        if (++cx.kc == a.cpt) {
-            cx.kc = 0;
-            ++cx.tap;
+        if (++cx.tap == a.n_taps) {
+            cx.tap = 0;
+            ++cx.kc;
         }
     } else {
         const int64_t g_rem = cx.g_end - cx.g_s;

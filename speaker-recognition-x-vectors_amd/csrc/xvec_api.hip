@@ -125,6 +125,7 @@ void fill_geometry(xvec_handle* h, TdnnGeom* geo, int chunk_pair) {
             g.kpt = g.cin;
             g.tap_stride_src = round_up(g.cin, chunk_pair);
         }
+        g.chunk_k = chunk_pair / 2;
         g.kpt_pad = round_up(g.kpt, chunk_pair);
         g.k_pad = g.n_taps * g.kpt_pad;
     }

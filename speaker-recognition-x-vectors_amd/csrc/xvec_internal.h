@@ -58,6 +58,7 @@ struct TdnnGeom {
     int tap_stride_src; // for packing: dest k of (tap, c) = tap*tap_stride + c
     int src_taps;       // taps in the PyTorch weight
     int src_cin;        // channels per tap in the PyTorch weight
+    int chunk_k;        // K elements per 128-byte chunk (32 fp32, 64 bf16): unit of the packed K order
 };
 
 struct TdnnArgs {

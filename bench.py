@@ -8,6 +8,11 @@ batch of 256 synthetic utterances already resident in HBM (BASELINE.json configs
 Every rank runs the same per-GPU workload (weak scaling); with N>1 the job ends with the one
 real exchange of the path, an RCCL all-gather of the [K*256, 512] fp32 embeddings, inside
 the timed region.  Rank 0 prints ONE JSON line.
+
+The other BASELINE configs are parity-test cases, not the bench line; they can still be timed:
+    --workload ragged     configs[2]: 256 utterances of 200-1000 frames, padded + lengths mask
+    --workload job        configs[3]: 100 000 utterances, sharded over the ranks, one all-gather (strong scaling)
+    --dtype bf16          configs[4]
 """
 import argparse
 import json
@@ -60,6 +65,12 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU-baseline work (0 = skip)")
     ap.add_argument("--dtype", choices=("fp32", "bf16"), default="fp32",
                     help="frame-level arithmetic; the headline (BASELINE configs[1]) is fp32")
+    ap.add_argument("--workload", choices=("fixed", "ragged", "job"), default="fixed",
+                    help="fixed: configs[1] (the bench line).  ragged: configs[2], one batch of utterances of "
+                         "200-1000 frames, zero-padded with a lengths mask.  job: configs[3], --utterances "
+                         "fixed-length utterances generated on the device batch by batch, sharded over the ranks, "
+                         "one all-gather at the end (--steps is derived)")
+    ap.add_argument("--utterances", type=int, default=100_000, help="job size of --workload job")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -79,31 +90,61 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     B, T, K, W = args.batch, args.frames, args.steps, args.warmup
+    lengths = None
+    n_local = None
+    if args.workload == "ragged":
+        lens_np = xa.synth.make_lengths(B)                  # default_rng(1234).integers(200, 1001, B)  
+        lengths = lens_np.tolist()
+        T = int(lens_np.max())
+    elif args.workload == "job":
+        lo, hi = xa.extract.shard_bounds(args.utterances, rank, world)
+        n_local = hi - lo
+        K = -(-(args.utterances // world + (1 if args.utterances % world else 0)) // B)   # batches of the largest shard
     sd = {k: torch.from_numpy(np.asarray(v)) for k, v in xa.synth.make_state_dict(seed=42).items()}
     model = xa.XVectorModel(precision=args.dtype)
     model.load_state_dict(sd)
     model = model.to(dev).eval()
     gen = torch.Generator(device=dev).manual_seed(1000 + rank)
     x = torch.randn((B, T, 24), generator=gen, device=dev, dtype=torch.float32)
-    emb = torch.empty((K * B, 512), device=dev, dtype=torch.float32)
-    gathered = torch.empty((world * K * B, 512), device=dev, dtype=torch.float32) if world > 1 else None
+    if lengths is not None:
+        x *= (torch.arange(T, device=dev)[None, :] < torch.tensor(lengths, device=dev)[:, None])[:, :, None]
+    emb = torch.empty((K * B, 512), device=dev, dtype=torch.float32) if n_local is None else None
+    gathered = torch.empty((world * K * B, 512), device=dev, dtype=torch.float32) if world > 1 and n_local is None else None
+
+    def step(k):
+        emb[k * B:(k + 1) * B] = model.extract_x_vec(x, lengths=lengths)
+
+    def job():
+        # the product's sharded job (extract.extract_sharded): contiguous utterance block per rank,
+        # batches generated on the device, one all_gather_into_tensor of the [N/W, 512] shards
+        return xa.extract.extract_sharded(
+            model.extract_x_vec,
+            lambda lo, hi: torch.randn((hi - lo, T, 24), generator=gen, device=dev, dtype=torch.float32),
+            args.utterances, batch_size=B)
 
     def barrier():
         if world > 1:
             dist.barrier()
 
     for _ in range(W):
-        model.extract_x_vec(x)
+        model.extract_x_vec(x, lengths=lengths)
     if world > 1:   # warm the collective too (communicator setup is not part of a step)
-        dist.all_gather_into_tensor(gathered, emb)
+        if n_local is None:
+            dist.all_gather_into_tensor(gathered, emb)
+        else:
+            xa.extract.gather_embeddings(torch.zeros((n_local, 512), device=dev), args.utterances)
     torch.cuda.synchronize(dev)
     barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    for k in range(K):
-        emb[k * B:(k + 1) * B] = model.extract_x_vec(x)
-    if world > 1:
-        dist.all_gather_into_tensor(gathered, emb)
+    if n_local is not None:
+        full = job()
+        assert full.shape == (args.utterances, 512)
+    else:
+        for k in range(K):
+            step(k)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, emb)
     torch.cuda.synchronize(dev)
     barrier()
     torch.cuda.synchronize(dev)
@@ -119,8 +160,9 @@ def main():
     out_host = torch.empty((B, 512), dtype=torch.float32).pin_memory()
     torch.cuda.synchronize(dev)
     t1 = time.perf_counter()
-    for k in range(K):
-        out_host.copy_(model.extract_x_vec(x_host.to(dev, non_blocking=True)), non_blocking=True)
+    K_pcie = min(K, 50)
+    for k in range(K_pcie):
+        out_host.copy_(model.extract_x_vec(x_host.to(dev, non_blocking=True), lengths=lengths), non_blocking=True)
     torch.cuda.synchronize(dev)
     dt_pcie = time.perf_counter() - t1
 
@@ -128,16 +170,27 @@ def main():
     model.set_profiling(True, dev)
     names = ("tdnn1", "tdnn2", "tdnn3", "tdnn4", "tdnn5_pool", "pool_finalize", "segment6")
     acc = {n: 0.0 for n in names}
-    for _ in range(K):
-        model.extract_x_vec(x)
+    for _ in range(min(K, 50)):
+        model.extract_x_vec(x, lengths=lengths)
         tm = model.timings_ms(dev)       # synchronises on the step's last event
         for n in names:
             acc[n] += tm[n]
     model.set_profiling(False, dev)
-    avg_ms = {n: acc[n] / K for n in names}
+    avg_ms = {n: acc[n] / min(K, 50) for n in names}
 
     if rank == 0:
-        lf = [f * B for f in layer_flops(T)]
+        if lengths is None:
+            lf = [f * B for f in layer_flops(T)]
+            n_done = world * K * B if n_local is None else args.utterances
+            frames_done = n_done * T
+            path_flops, path_bytes = total_flops(T), BYTES_PER_UTT * T / 300.0
+        else:                                       # per-utterance lengths: sum the per-layer FLOPs
+            per = [layer_flops(t) for t in lengths]
+            lf = [sum(p[i] for p in per) for i in range(5)]
+            n_done = world * K * B
+            frames_done = world * K * sum(lengths)
+            path_flops = (sum(lf) + B * 2 * 3000 * 512) / B
+            path_bytes = BYTES_PER_UTT * (sum(lengths) / B) / 300.0
         tdnn_names = names[:5]
         tdnn_ms = sum(avg_ms[n] for n in tdnn_names)
         # dominant kernel: the plain tdnn_f32_kernel instance (layers 2-4 launch the same code object)
@@ -148,7 +201,7 @@ def main():
         peak = BF16_MFMA_PEAK if bf else FP32_MFMA_PEAK
         dom_kernel = ("xvec::tdnn_kernel<false,false,true,true,true> (layers 2-4, bf16 MFMA)" if bf else
                       "xvec::tdnn_kernel<false,false,true,false,false> (layers 2-4, fp32 MFMA)")
-        value = world * K * B / dt
+        value = n_done / dt
         # HBM bytes per launch of the dominant kernel come from the committed rocprofv3 --pmc pass of
         # this same command (profiles/traffic.json, written by profiles/summarize_pmc.py); counters
         # cannot be collected from inside the benchmark process.
@@ -163,12 +216,17 @@ def main():
         out = {
             "metric": "x-vector embeddings/sec (300-frame utt)", "value": round(value, 1), "unit": "embeddings/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(dt / K * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.dtype == "fp32" else "bf16", "data": "synthetic",
-            "config": {"workload": f"configs[{1 if args.dtype == 'fp32' else 4}]: 1xMI355X batch={B} fixed {T}-frame x 24-MFCC "
-                                   f"utterances, {args.dtype} frame-level stack, "
-                                   "extract_x_vec layer 6, random-init weights seed 42",
-                       "batch_per_gpu": B, "frames": T,
-                       "pcie_inclusive_embeddings_per_s_per_gpu": round(K * B / dt_pcie, 1),
+            "higher_is_better": True, "scaling": "strong" if n_local is not None else "weak", "vs_baseline": None, "dtype": "f32" if args.dtype == "fp32" else "bf16", "data": "synthetic",
+            "config": {"workload": {
+                           "fixed": f"configs[{1 if args.dtype == 'fp32' else 4}]: 1xMI355X batch={B} fixed {T}-frame x 24-MFCC "
+                                    f"utterances, {args.dtype} frame-level stack, ",
+                           "ragged": f"configs[2]: batch={B} utterances of 200-1000 frames (numpy default_rng(1234)), zero-padded "
+                                     f"to {T} with a lengths mask, {args.dtype}, ",
+                           "job": f"configs[3]: {args.utterances} utterances of {T} frames generated on the device batch by "
+                                  f"batch ({B}), sharded over {world} rank(s), {args.dtype}, "}[args.workload]
+                                   + "extract_x_vec layer 6, random-init weights seed 42",
+                       "batch_per_gpu": B, "frames": T, "valid_frames_per_s": round(frames_done / dt, 1),
+                       "pcie_inclusive_embeddings_per_s_per_gpu": round(K_pcie * B / dt_pcie, 1),
                        "sharding": f"utterance-sharded x{world}"
                        + (", one all-gather of [K*B,512] fp32 in the timed region" if world > 1 else "")},
             "roofline": {
@@ -179,8 +237,8 @@ def main():
                 "per_kernel_ms": {n: round(v, 4) for n, v in avg_ms.items()},
                 "per_kernel_tflops": {n: round(lf[i] / (avg_ms[n] * 1e-3) / 1e12, 2) for i, n in enumerate(tdnn_names)},
                 "tdnn_stack_tflops": round(sum(lf) / (tdnn_ms * 1e-3) / 1e12, 2),
-                "path_flop_frac_of_peak": round(value / world * total_flops(T) / peak, 4),
-                "path_hbm_frac_algorithmic": round(value / world * BYTES_PER_UTT / HBM_PEAK, 4),
+                "path_flop_frac_of_peak": round(value / world * path_flops / peak, 4),
+                "path_hbm_frac_algorithmic": round(value / world * path_bytes / HBM_PEAK, 4),
             },
         }
         if world == 1 and args.cpu_budget > 0:

@@ -6,7 +6,8 @@ hand-written gfx950 HIP kernels behind the C-ABI in include/xvec_hip.h.
 """
 from . import synth  # noqa: F401  (numpy only)
 
-__all__ = ["synth", "XVectorModel", "TdnnLayer", "get_time_context", "MfccFrontEnd", "hip", "extract", "frontend"]
+__all__ = ["synth", "XVectorModel", "TdnnLayer", "get_time_context", "MfccFrontEnd", "PldaScorer", "hip", "extract",
+           "frontend", "scoring"]
 
 
 def __getattr__(name):
@@ -17,7 +18,10 @@ def __getattr__(name):
     if name == "MfccFrontEnd":
         from . import frontend
         return frontend.MfccFrontEnd
-    if name in ("hip", "model", "extract", "frontend"):
+    if name == "PldaScorer":
+        from . import scoring
+        return scoring.PldaScorer
+    if name in ("hip", "model", "extract", "frontend", "scoring"):
         import importlib
         return importlib.import_module("." + name, __name__)
     raise AttributeError(name)

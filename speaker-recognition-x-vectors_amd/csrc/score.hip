@@ -1,0 +1,324 @@
+// Scoring back end (next row N4): fp64 score matrices on v_mfma_f64_16x16x4_f64.
+//   reference: plda_classifier.py:81-87 (fast_PLDA_scoring of speechbrain 0.5.12, numpy float64)
+// C ABI: include/xvec_score.h.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+
+#include "../../include/xvec_hip.h"
+#include "../../include/xvec_score.h"
+#include "tdnn_common.h"
+
+namespace xvec {
+namespace {
+
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kSM = 128;   // block tile rows (of A)
+constexpr int kSN = 128;   // block tile cols (rows of B)
+constexpr int kSK = 16;    // K chunk: 16 doubles = one 128-byte row piece
+constexpr int kSLD = 18;   // LDS row stride in doubles (144 B): ds_read_b64 fragments of 16 rows x 2 k
+                           // then hit 32 distinct even banks, and rows stay 16-byte aligned
+
+struct GemmArgs {
+    const double* A;
+    const double* B;
+    const double* rowv;
+    const double* colv;
+    double* C;
+    int64_t lda, ldb, ldc, M, N;
+    int K, tiles_n;
+    double cst, scale;
+};
+
+// two consecutive doubles of row `row` at column k (zero outside the matrix)
+template <bool VEC>
+__device__ __forceinline__ f64x2 load2(const double* __restrict__ P, int64_t ld, int64_t rows, int K, int64_t row,
+                                       int k) {
+    f64x2 v = {0.0, 0.0};
+    if (row < rows) {
+        const double* p = P + row * ld + k;
+        if (VEC) {
+            if (k < K) v = *reinterpret_cast<const f64x2*>(p);   // K even: k+1 < K as well
+        } else {
+            if (k < K) v.x = p[0];
+            if (k + 1 < K) v.y = p[1];
+        }
+    }
+    return v;
+}
+
+// 4 waves as 2x2, each 64x64 = 4x4 MFMA tiles of 16x16 (C/D: col = lane&15, row = (lane>>4) + 4*reg).
+// K in 16-wide chunks through double-buffered LDS; the next chunk's global loads are in flight
+// while the 64 MFMAs (64 cycles each) of the current one run, so the kernel is matrix-pipe bound.
+template <bool VEC>
+__global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(const GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);     // the column tiles of one row tile share an XCD's L2
+    const int64_t m0 = (int64_t)(lid / g.tiles_n) * kSM;
+    const int64_t n0 = (int64_t)(lid % g.tiles_n) * kSN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1, l15 = lane & 15, l4 = lane >> 4;
+    const int piece = tid & 7, row0 = tid >> 3;
+
+    double* sA = sm;                          // [2][kSM][kSLD]
+    double* sB = sm + 2 * kSM * kSLD;         // [2][kSN][kSLD]
+
+    f64x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
+
+    f64x2 ra[4], rb[4];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            ra[p] = load2<VEC>(g.A, g.lda, g.M, g.K, m0 + row0 + 32 * p, k0 + 2 * piece);
+            rb[p] = load2<VEC>(g.B, g.ldb, g.N, g.K, n0 + row0 + 32 * p, k0 + 2 * piece);
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            *reinterpret_cast<f64x2*>(sA + (buf * kSM + row0 + 32 * p) * kSLD + 2 * piece) = ra[p];
+            *reinterpret_cast<f64x2*>(sB + (buf * kSN + row0 + 32 * p) * kSLD + 2 * piece) = rb[p];
+        }
+    };
+
+    const int n_chunks = (g.K + kSK - 1) / kSK;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int c = 0; c < n_chunks; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < n_chunks) gload((c + 1) * kSK);
+        const double* a_base = sA + (buf * kSM + wr * 64 + l15) * kSLD + l4;
+        const double* b_base = sB + (buf * kSN + wc * 64 + l15) * kSLD + l4;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            double a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                a[i] = a_base[i * 16 * kSLD + kk * 4];
+                b[i] = b_base[i * 16 * kSLD + kk * 4];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (c + 1 < n_chunks) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: + rowv[m] + colv[n] + cst, * scale; 16 lanes write 128 contiguous bytes
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int64_t n = n0 + wc * 64 + j * 16 + l15;
+        if (n >= g.N) continue;
+        const double cv = (g.colv ? g.colv[n] : 0.0) + g.cst;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t m = m0 + wr * 64 + i * 16 + l4 + 4 * r;
+                if (m < g.M) {
+                    const double rv = g.rowv ? g.rowv[m] : 0.0;
+                    g.C[m * g.ldc + n] = g.scale * (acc[i][j][r] + rv + cv);
+                }
+            }
+        }
+    }
+}
+
+// out[i,d] = x[i,d] - mean[d]
+__global__ void center_rows_kernel(const double* __restrict__ x, const double* __restrict__ mean, int64_t n, int dim,
+                                   double* __restrict__ out) {
+    const int64_t total = n * dim;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = x[i] - mean[i % dim];
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// out[i] = 0.5 * <a_i, b_i>   (one wave per row)
+__global__ void half_rowdot_kernel(const double* __restrict__ a, int64_t lda, const double* __restrict__ b, int64_t ldb,
+                                   int64_t n, int dim, double* __restrict__ out) {
+    const int64_t row = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const int lane = threadIdx.x & 63;
+    double s = 0.0;
+    for (int d = lane; d < dim; d += 64) s = fma(a[row * lda + d], b[row * ldb + d], s);
+    s = wave_sum(s);
+    if (lane == 0) out[row] = 0.5 * s;
+}
+
+// out[i,:] = x[i,:] / |x[i,:]|   (one wave per row; a zero row stays zero)
+__global__ void normalize_rows_kernel(const double* __restrict__ x, int64_t n, int dim, double* __restrict__ out) {
+    const int64_t row = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const int lane = threadIdx.x & 63;
+    double s = 0.0;
+    for (int d = lane; d < dim; d += 64) s = fma(x[row * dim + d], x[row * dim + d], s);
+    s = wave_sum(s);
+    const double inv = s > 0.0 ? 1.0 / sqrt(s) : 0.0;
+    for (int d = lane; d < dim; d += 64) out[row * dim + d] = x[row * dim + d] * inv;
+}
+
+thread_local char g_serr[384] = "";
+
+int sfail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_serr, sizeof(g_serr), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int check_launch(const char* what) {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return sfail(XVEC_ERR_HIP, "%s launch failed: %s", what, hipGetErrorString(e));
+    return XVEC_OK;
+}
+
+int gemm_nt(const double* A, int64_t lda, const double* B, int64_t ldb, int64_t M, int64_t N, int K,
+            const double* rowv, const double* colv, double cst, double scale, double* C, int64_t ldc, hipStream_t s) {
+    if (M == 0 || N == 0) return XVEC_OK;
+    const int64_t tm = (M + kSM - 1) / kSM, tn = (N + kSN - 1) / kSN;
+    if (tm * tn > 0x7fffffff) return sfail(XVEC_ERR_ARG, "score matrix too large for one launch");
+    GemmArgs g{A, B, rowv, colv, C, lda, ldb, ldc, M, N, K, (int)tn, cst, scale};
+    const size_t lds = (size_t)2 * (kSM + kSN) * kSLD * sizeof(double);
+    const bool vec = (K % 2 == 0) && (lda % 2 == 0) && (ldb % 2 == 0) && (reinterpret_cast<uintptr_t>(A) % 16 == 0) &&
+                     (reinterpret_cast<uintptr_t>(B) % 16 == 0);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_f64_kernel<true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_f64_kernel<false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    if (vec)
+        gemm_nt_f64_kernel<true><<<(unsigned)(tm * tn), 256, lds, s>>>(g);
+    else
+        gemm_nt_f64_kernel<false><<<(unsigned)(tm * tn), 256, lds, s>>>(g);
+    return check_launch("gemm_nt_f64_kernel");
+}
+
+inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+struct ScorePlan {
+    double *ec, *tc, *uv, *w, *mp, *sp;
+    size_t total;
+};
+
+ScorePlan make_score_plan(void* ws, int64_t ne, int64_t nt, int dim) {
+    ScorePlan p{};
+    char* base = static_cast<char*>(ws);
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        double* ptr = reinterpret_cast<double*>(base + off);
+        off += align256(bytes);
+        return ptr;
+    };
+    p.ec = take((size_t)ne * dim * 8);        // centred / normalised enrol vectors
+    p.tc = take((size_t)nt * dim * 8);        // ... test vectors
+    p.uv = take((size_t)ne * 2 * dim * 8);    // [ e Psi | e Phi ]
+    p.w = take((size_t)nt * dim * 8);         // t Phi
+    p.mp = take((size_t)ne * 8);
+    p.sp = take((size_t)nt * 8);
+    p.total = off;
+    return p;
+}
+
+}  // namespace
+}  // namespace xvec
+
+using namespace xvec;
+
+extern "C" {
+
+const char* xvec_score_last_error(void) { return g_serr; }
+
+int xvec_gemm_nt_f64(const double* A, int64_t lda, const double* B, int64_t ldb, int64_t M, int64_t N, int32_t K,
+                     const double* rowv, const double* colv, double cst, double scale, double* C, int64_t ldc,
+                     xvec_stream stream) {
+    if (M < 0 || N < 0 || K < 1) return sfail(XVEC_ERR_ARG, "bad GEMM shape M=%lld N=%lld K=%d", (long long)M, (long long)N, K);
+    if ((M && !A) || (N && !B) || (M && N && !C)) return sfail(XVEC_ERR_ARG, "null matrix pointer");
+    if (lda < K || ldb < K || ldc < N) return sfail(XVEC_ERR_ARG, "row stride smaller than the row");
+    return gemm_nt(A, lda, B, ldb, M, N, K, rowv, colv, cst, scale, C, ldc, static_cast<hipStream_t>(stream));
+}
+
+size_t xvec_score_workspace_bytes(int64_t n_enroll, int64_t n_test, int32_t dim) {
+    if (n_enroll < 0 || n_test < 0 || dim < 1) return 0;
+    return make_score_plan(nullptr, n_enroll, n_test, dim).total;
+}
+
+int xvec_plda_score(const double* enroll, int64_t n_enroll, const double* test, int64_t n_test, int32_t dim,
+                    const double* mean, const double* psi_t, const double* phi_t, double plda_cst,
+                    double scaling_factor, double* scores, void* workspace, size_t workspace_bytes,
+                    xvec_stream stream) {
+    const bool self = (test == nullptr);
+    if (self) n_test = n_enroll;
+    if (n_enroll < 1 || n_test < 1 || dim < 1) return sfail(XVEC_ERR_ARG, "empty enrol/test set or dim < 1");
+    if (!enroll || !mean || !psi_t || !phi_t || !scores || !workspace) return sfail(XVEC_ERR_ARG, "null pointer");
+    const ScorePlan p = make_score_plan(workspace, n_enroll, self ? 0 : n_test, dim);
+    if (workspace_bytes < p.total)
+        return sfail(XVEC_ERR_WORKSPACE, "workspace too small: %zu < %zu bytes", workspace_bytes, p.total);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int rc;
+    // centre (StatObject_SB.center_stat1)
+    center_rows_kernel<<<1024, 256, 0, s>>>(enroll, mean, n_enroll, dim, p.ec);
+    if ((rc = check_launch("center_rows_kernel"))) return rc;
+    // [e Psi | e Phi]: one GEMM against the stacked [Psi^T ; Phi^T] is two calls on the same A
+    if ((rc = gemm_nt(p.ec, dim, psi_t, dim, n_enroll, dim, dim, nullptr, nullptr, 0.0, 1.0, p.uv, 2 * dim, s))) return rc;
+    if ((rc = gemm_nt(p.ec, dim, phi_t, dim, n_enroll, dim, dim, nullptr, nullptr, 0.0, 1.0, p.uv + dim, 2 * dim, s))) return rc;
+    const unsigned rb_e = (unsigned)((n_enroll + 3) / 4);
+    half_rowdot_kernel<<<rb_e, 256, 0, s>>>(p.uv + dim, 2 * dim, p.ec, dim, n_enroll, dim, p.mp);   // model_part
+    if ((rc = check_launch("half_rowdot_kernel"))) return rc;
+    const double* tc = p.ec;
+    const double* sp = p.mp;
+    if (!self) {
+        center_rows_kernel<<<1024, 256, 0, s>>>(test, mean, n_test, dim, p.tc);
+        if ((rc = check_launch("center_rows_kernel"))) return rc;
+        if ((rc = gemm_nt(p.tc, dim, phi_t, dim, n_test, dim, dim, nullptr, nullptr, 0.0, 1.0, p.w, dim, s))) return rc;
+        half_rowdot_kernel<<<(unsigned)((n_test + 3) / 4), 256, 0, s>>>(p.w, dim, p.tc, dim, n_test, dim, p.sp);   // seg_part
+        if ((rc = check_launch("half_rowdot_kernel"))) return rc;
+        tc = p.tc;
+        sp = p.sp;
+    }
+    // scores = scaling * (model_part[:,None] + seg_part[None,:] + plda_cst + (e Psi) t^T)
+    return gemm_nt(p.uv, 2 * dim, tc, dim, n_enroll, n_test, dim, p.mp, sp, plda_cst, scaling_factor, scores, n_test, s);
+}
+
+int xvec_cosine_score(const double* enroll, int64_t n_enroll, const double* test, int64_t n_test, int32_t dim,
+                      double* scores, void* workspace, size_t workspace_bytes, xvec_stream stream) {
+    const bool self = (test == nullptr);
+    if (self) n_test = n_enroll;
+    if (n_enroll < 1 || n_test < 1 || dim < 1) return sfail(XVEC_ERR_ARG, "empty enrol/test set or dim < 1");
+    if (!enroll || !scores || !workspace) return sfail(XVEC_ERR_ARG, "null pointer");
+    const ScorePlan p = make_score_plan(workspace, n_enroll, self ? 0 : n_test, dim);
+    if (workspace_bytes < p.total)
+        return sfail(XVEC_ERR_WORKSPACE, "workspace too small: %zu < %zu bytes", workspace_bytes, p.total);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int rc;
+    normalize_rows_kernel<<<(unsigned)((n_enroll + 3) / 4), 256, 0, s>>>(enroll, n_enroll, dim, p.ec);
+    if ((rc = check_launch("normalize_rows_kernel"))) return rc;
+    const double* tc = p.ec;
+    if (!self) {
+        normalize_rows_kernel<<<(unsigned)((n_test + 3) / 4), 256, 0, s>>>(test, n_test, dim, p.tc);
+        if ((rc = check_launch("normalize_rows_kernel"))) return rc;
+        tc = p.tc;
+    }
+    return gemm_nt(p.ec, dim, tc, dim, n_enroll, n_test, dim, nullptr, nullptr, 0.0, 1.0, scores, n_test, s);
+}
+
+}  // extern "C"

@@ -220,6 +220,44 @@ def test_full_size_ragged(gpu_model, sd42, synth):
     assert_parity(out[i:i + 1], ref, 1e-4, "shortest vs oracle")
 
 
+@pytest.mark.parametrize("precision,tol", [("fp32", 1e-4), ("bf16", 1e-2)])
+def test_extreme_shapes(sd42, synth, precision, tol):
+    """Shapes far from the bench batch: one very long utterance (its pooling partials span ~940
+    row groups and every persistent block), thousands of minimal utterances (several utterances
+    inside one 32-row group), and a batch at the documented maximum count."""
+    import xvector_amd as xa
+    m = xa.XVectorModel(precision=precision)
+    m.load_state_dict(sd42)
+    m = m.to(DEV)
+    p32 = float_params(sd42)
+    # (1) B=1, T=30 000 (five minutes of speech)
+    x = synth.make_mfcc(1, 30000, seed=5)
+    with torch.no_grad():
+        ref = oracle.extract_x_vec(torch.from_numpy(x), p32)
+    assert_parity(m.extract_x_vec(_gpu(x)), ref, tol, "T=30000", elem_tol=None if precision == "fp32" else 2e-2)
+    # (2) 3 000 utterances of 16..40 frames, ragged: 2..26 pooled frames each
+    rng = np.random.default_rng(9)
+    lens = rng.integers(16, 41, 3000)
+    xs = synth.make_mfcc(3000, 40, seed=6)
+    out = m.extract_x_vec(_gpu(xs), lengths=lens.tolist())
+    assert out.shape == (3000, 512) and torch.isfinite(out).all()
+    idx = [0, 1, 2, 1499, 2998, 2999, int(lens.argmin()), int(lens.argmax())]
+    with torch.no_grad():
+        ref = torch.cat([oracle.extract_x_vec(torch.from_numpy(xs[i:i + 1, :int(lens[i])]), p32) for i in idx])
+    assert_parity(out[idx], ref, tol, "short ragged", elem_tol=None if precision == "fp32" else 3e-2)
+    # (3) the largest batch one call accepts (65 535 utterances), T=16: every row equals the
+    # same utterance run alone
+    big = torch.from_numpy(synth.make_mfcc(5, 16, seed=7)).to(DEV).repeat(13107, 1, 1)
+    assert big.shape[0] == 65535
+    outb = m.extract_x_vec(big)
+    alone = m.extract_x_vec(big[:5])
+    assert_parity(outb[:5], alone, 1e-5, "max batch head")
+    assert_parity(outb[-5:], alone, 1e-5, "max batch tail")
+    assert torch.equal(outb[5:10], outb[65530:65535])
+    with pytest.raises((ValueError, RuntimeError), match="65535"):
+        m.extract_x_vec(torch.zeros(65536, 16, 24, device=DEV))
+
+
 def test_errors_are_loud(gpu_model):
     with pytest.raises(RuntimeError):
         gpu_model.extract_x_vec(torch.zeros(1, 300, 24))           # CPU tensor: no fallback

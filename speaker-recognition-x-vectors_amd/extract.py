@@ -109,15 +109,84 @@ def to_records(x_vecs: torch.Tensor, labels, ids) -> List[tuple]:
     return [(i, int(l), np.array(v, dtype=np.float64)) for v, l, i in zip(host, labels, ids)]
 
 
+def stream_x_vectors(model, host_batches: Iterable[torch.Tensor], device=None, depth: int = 2):
+    """Overlapped extraction from HOST batches: yields the fp32 [B, D] x-vectors of every batch as
+    host tensors, in input order.
+
+    Batch k+1 is copied host->device on a side stream while batch k runs on the caller's current
+    stream; results stay on the device until `depth` younger batches have been enqueued and are
+    then fetched with one plain copy each on a third stream (by then the batch has long finished, so
+    the host never waits for compute).  Measured alternatives that lost on this ROCm stack
+    (profiles/diag/stream_probe*.py): non-blocking result copies into pinned buffers made their
+    enqueue block (3.65 vs 2.91 ms per batch), and results parked in pinned host buffers cost ~9 ms per
+    512 KiB when the CPU reads them back (uncached mapping).  Device input slots are a small ring
+    allocated once per shape (an allocation inside the loop would reach hipMalloc, which
+    synchronises the device).  Host batches may be pinned or pageable, and float64 (what the
+    reference's DataLoader yields, main.py:137): the cast to fp32 happens on the device, as in
+    test_step."""
+    dev = torch.device(device) if device is not None else next(model.parameters()).device
+    if dev.type != "cuda":
+        raise RuntimeError("stream_x_vectors: the model must live on a HIP device")
+    compute = torch.cuda.current_stream(dev)
+    h2d, d2h = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    n_in = depth + 1
+    slots = [None] * n_in      # device inputs
+    consumed = [None] * n_in   # event: the batch that read the slot has been computed
+    inflight = []              # (event, device result)
+
+    def retire():
+        ev, out = inflight.pop(0)
+        ev.synchronize()
+        with torch.cuda.stream(d2h):               # not the compute stream: there the copy would queue
+            return out.cpu()                       # behind the younger batches already enqueued
+
+    k = 0
+    for xb in host_batches:
+        if xb.device.type != "cpu":
+            raise ValueError("stream_x_vectors: expected host tensors (device batches: call extract_x_vec directly)")
+        i = k % n_in
+        fresh = slots[i] is None or slots[i].shape != xb.shape or slots[i].dtype != xb.dtype
+        if fresh:
+            slots[i] = None
+            slots[i] = torch.empty(xb.shape, dtype=xb.dtype, device=dev)   # from the current stream's pool
+        with torch.cuda.stream(h2d):
+            if fresh:
+                h2d.wait_stream(compute)           # whatever used that memory before is done
+            elif consumed[i] is not None:
+                h2d.wait_event(consumed[i])        # the slot's previous batch has been read
+            slots[i].copy_(xb, non_blocking=True)
+            arrived = torch.cuda.Event()
+            arrived.record(h2d)
+        compute.wait_event(arrived)
+        out = model.extract_x_vec(slots[i])        # enqueued on the current stream
+        done = torch.cuda.Event()
+        done.record(compute)
+        consumed[i] = done
+        inflight.append((done, out))
+        k += 1
+        if len(inflight) > depth:
+            yield retire()
+    while inflight:
+        yield retire()
+    compute.wait_stream(h2d)                       # the slots return to the current stream's pool
+
+
 def extract_x_vectors(model, loader: Iterable) -> List[tuple]:
     """Lightning-free stand-in for `trainer.test(model)` in extraction mode
-    (main.py:237-267): runs model.test_step on every batch and collects the records the
-    reference accumulates in its module-global `x_vector` list."""
+    (main.py:237-267): every (samples, labels, ids) batch of the loader goes through the overlapped
+    pipeline above (same arithmetic as model.test_step: cast to fp32, extract_x_vec) and the
+    records the reference accumulates in its module-global `x_vector` list come back in order."""
     records: List[tuple] = []
-    dev = next(model.parameters()).device
-    for bi, (samples, labels, ids) in enumerate(loader):
-        for x_vec, lab, idd in model.test_step((samples.to(dev), labels, ids), bi):
-            records.extend(to_records(x_vec, lab, idd))
+    meta = []
+
+    def samples():
+        for batch_samples, labels, ids in loader:
+            meta.append((labels, ids))
+            yield batch_samples if torch.is_tensor(batch_samples) else torch.as_tensor(batch_samples)
+
+    for k, host in enumerate(stream_x_vectors(model, samples())):
+        labels, ids = meta[k]
+        records.extend(to_records(host, labels, ids))
     return records
 
 

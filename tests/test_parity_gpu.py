@@ -163,6 +163,24 @@ def test_g7_caller_contract(gpu_model, synth):
     assert_parity(vecs, g["out_vecs"], 1e-4, "caller vectors")
 
 
+def test_streamed_extraction_from_host_batches(gpu_model, synth):
+    """extract.stream_x_vectors (next batch's H2D overlapped with compute): same vectors, same
+    order as the direct calls; float64 host batches as the reference's DataLoader yields them."""
+    from xvector_amd import extract
+    sizes = [7, 64, 1, 33, 64, 64, 5]
+    batches = [torch.from_numpy(synth.make_mfcc(b, 299, seed=40 + i)).double() for i, b in enumerate(sizes)]
+    got = list(extract.stream_x_vectors(gpu_model, iter(batches), depth=2))
+    assert [g.shape[0] for g in got] == sizes and all(g.device.type == "cpu" for g in got)
+    for g, xb in zip(got, batches):
+        assert torch.equal(g, gpu_model.extract_x_vec(xb.to(DEV).float()).cpu())
+    # pinned input, deeper pipeline
+    pinned = [b.float().pin_memory() for b in batches]
+    got2 = list(extract.stream_x_vectors(gpu_model, iter(pinned), depth=4))
+    assert all(torch.equal(a, b) for a, b in zip(got, got2))
+    with pytest.raises(ValueError):
+        list(extract.stream_x_vectors(gpu_model, iter([batches[0].to(DEV)])))
+
+
 def test_odd_input_width_and_short_utterances(synth):
     """input_size not a multiple of 4 (row padding kernel) and the shortest legal T=15
     (one pooled frame -> NaN std in the reference too)."""

@@ -19,61 +19,89 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return base + local;
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// Pooling cursor of a block: the utterance that holds the first row of the next 32-row group, and
+// the compact row where it ends.  Rows only grow along a block's range, so it advances with a few
+// scalar steps per group instead of a 64-bit division / binary search each time.
+struct PoolCur {
+    int u;
+    int64_t end;
+};
+
+template <bool RAGGED>
+__device__ __forceinline__ int64_t pool_first_row(const RowMap& m, int u) {
+    if (RAGGED) return m.offsets[u] - (int64_t)u * m.cum;
+    return (int64_t)u * (m.fixed_T - m.cum);
+}
+
 // Fused statistics-pooling partial (main.py:59-63) of one 32-row group held in one accumulator:
 // for every utterance overlapping compact rows [row_g, row_g+32), the mean and M2 (sum of squared
 // deviations about that mean) of this lane's column over the utterance's frames in the group.
+// The epilogue's vector instructions only issue in the gaps the partner wave's MFMA stream leaves
+// on the SIMD, so their COUNT is what matters: paired (v_pk_*) arithmetic where the whole group
+// belongs to one utterance, 0/1 row weights from one bit mask where it does not.
 template <bool RAGGED>
-__device__ __forceinline__ void pool_group_impl(const TdnnArgs& a, const f32x16& v, int64_t row_g, int h, int col) {
+__device__ __forceinline__ void pool_group_impl(const TdnnArgs& a, const f32x16& v, int64_t row_g, int h, int col,
+                                                float c, PoolCur& pc) {
     const int64_t grp = row_g >> 5;
     const RowMap& m = a.out_map;
-    const int64_t t_out = m.fixed_T - m.cum;
-    auto first_row = [&](int u) -> int64_t {
-        if (RAGGED) return m.offsets[u] - (int64_t)u * m.cum;
-        return (int64_t)u * t_out;
-    };
-    int u0;
-    if (RAGGED) {
-        u0 = utt_of_row(m, row_g);
-    } else {
-        const int64_t q = row_g / t_out;
-        u0 = (int)(q < m.n_utts - 1 ? q : m.n_utts - 1);
+    while (pc.end <= row_g && pc.u < m.n_utts - 1) {
+        ++pc.u;
+        pc.end = pool_first_row<RAGGED>(m, pc.u + 1);
     }
-    for (int u = u0; u < m.n_utts; ++u) {
-        const int64_t off = first_row(u);
+    if (pc.end >= row_g + 32) {               // whole group inside utterance pc.u: no masks
+        f32x2 sv = {0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 16; e += 2) sv += f32x2{v[e], v[e + 1]};
+        float s = sv.x + sv.y;
+        s += __shfl_xor(s, 32);
+        const float mean = s * (1.f / 32.f);
+        const f32x2 mv = {mean, mean};
+        f32x2 qv = {0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 16; e += 2) {
+            const f32x2 d = f32x2{v[e], v[e + 1]} - mv;
+            qv = __builtin_elementwise_fma(d, d, qv);
+        }
+        float m2 = qv.x + qv.y;
+        m2 += __shfl_xor(m2, 32);
+        if (h == 0) {
+            float* part = a.pool_part + (grp + pc.u) * (int64_t)(2 * a.ldy);
+            part[col] = mean;
+            part[a.ldy + col] = m2;
+        }
+        return;
+    }
+    for (int u = pc.u; u < m.n_utts; ++u) {
+        const int64_t off = pool_first_row<RAGGED>(m, u);
         if (off >= row_g + 32) break;
-        const int64_t end = first_row(u + 1);
+        const int64_t end = pool_first_row<RAGGED>(m, u + 1);
         const int64_t lo_r = off > row_g ? off : row_g;
         const int64_t hi_r = end < row_g + 32 ? end : row_g + 32;
         if (hi_r <= lo_r) continue;
-        const int lo_l = (int)(lo_r - row_g), hi_l = (int)(hi_r - row_g);   // local rows [lo_l, hi_l)
-        float s = 0.f, m2 = 0.f, mean;
-        if (lo_l == 0 && hi_l == 32) {        // whole group inside one utterance: no masks
+        const int lo_l = (int)(lo_r - row_g), hi_l = (int)(hi_r - row_g);   // local rows [lo_l, hi_l), 0 <= lo_l < hi_l <= 32
+        // bit r of rowmask = local row r belongs to utterance u; this lane's rows are
+        // (e&3) + 8*(e>>2) + 4*h, i.e. bits (e&3) + 8*(e>>2) of the mask shifted by 4*h
+        const unsigned below_hi = hi_l >= 32 ? 0xffffffffu : ((1u << hi_l) - 1u);
+        const unsigned rowmask = below_hi & ~((1u << lo_l) - 1u);
+        const unsigned lm = rowmask >> (4 * h);
+        // one pass, shifted by c (the column's BatchNorm shift: every value is relu(.)*scale + c, so
+        // the mean lies within about one standard deviation of c and s2 - s1^2/n does not cancel)
+        float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) s += v[e];
-            s += __shfl_xor(s, 32);
-            mean = s * (1.f / 32.f);
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const float d = v[e] - mean;
-                m2 = fmaf(d, d, m2);
-            }
-        } else {
-            const float inv_cnt = 1.f / (float)(hi_l - lo_l);
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int lr = (e & 3) + 8 * (e >> 2) + 4 * h;
-                s += (lr >= lo_l && lr < hi_l) ? v[e] : 0.f;
-            }
-            s += __shfl_xor(s, 32);
-            mean = s * inv_cnt;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int lr = (e & 3) + 8 * (e >> 2) + 4 * h;
-                const float d = v[e] - mean;
-                m2 += (lr >= lo_l && lr < hi_l) ? d * d : 0.f;
-            }
+        for (int e = 0; e < 16; ++e) {
+            const float w = (float)((lm >> ((e & 3) + 8 * (e >> 2))) & 1u);
+            const float d = v[e] - c;
+            const float t = w * d;
+            s1 += t;
+            s2 = fmaf(t, d, s2);
         }
-        m2 += __shfl_xor(m2, 32);
+        s1 += __shfl_xor(s1, 32);
+        s2 += __shfl_xor(s2, 32);
+        const float dm = s1 * (1.f / (float)(hi_l - lo_l));
+        const float mean = c + dm;
+        const float m2 = fmaxf(s2 - s1 * dm, 0.f);
         if (h == 0) {
             float* part = a.pool_part + (grp + u) * (int64_t)(2 * a.ldy);
             part[col] = mean;
@@ -83,9 +111,18 @@ __device__ __forceinline__ void pool_group_impl(const TdnnArgs& a, const f32x16&
 }
 
 // (two code paths: see set_tile_rows in tdnn_layer.hip)
-__device__ __forceinline__ void pool_group(const TdnnArgs& a, const f32x16& v, int64_t row_g, int h, int col) {
-    if (a.out_map.offsets == nullptr) pool_group_impl<false>(a, v, row_g, h, col);
-    else pool_group_impl<true>(a, v, row_g, h, col);
+__device__ __forceinline__ void pool_group(const TdnnArgs& a, const f32x16& v, int64_t row_g, int h, int col, float c,
+                                           PoolCur& pc) {
+    if (a.out_map.offsets == nullptr) pool_group_impl<false>(a, v, row_g, h, col, c, pc);
+    else pool_group_impl<true>(a, v, row_g, h, col, c, pc);
+}
+
+// cursor for a block whose first group starts at compact row `row`
+__device__ __forceinline__ PoolCur pool_cursor(const TdnnArgs& a, int64_t row) {
+    PoolCur pc;
+    pc.u = __builtin_amdgcn_readfirstlane(utt_of_row(a.out_map, row));
+    pc.end = row_off(a.out_map, pc.u + 1);
+    return pc;
 }
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {

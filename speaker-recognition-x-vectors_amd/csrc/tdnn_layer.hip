@@ -65,6 +65,7 @@ struct Ctx {
     int64_t off_next;
     int64_t m0;          // first flat row of the tile the load stream is in
     int64_t g_s, g_end;  // that tile's first row group; end of this block's row range
+    PoolCur pool;        // compute side: pooling cursor (POOL variants)
     int tap, kc, itl;    // next chunk to fetch: (tap, kc) and its linear index within the tile
     int es;              // bytes per input element (4: fp32, 2: bf16)
 };
@@ -366,7 +367,7 @@ __device__ __forceinline__ void process_tile(const TdnnArgs& a, float* smem, Ctx
                 }                                                                                         \
             }                                                                                             \
         }                                                                                                 \
-        if (POOL) pool_group(a, acc##i_, m0 + i_ * 32, h, col);                                           \
+        if (POOL) pool_group(a, acc##i_, m0 + i_ * 32, h, col, sh, cx.pool);                                           \
     }
     XV_EPI(0) XV_EPI(1) XV_EPI(2) XV_EPI(3)
 #undef XV_EPI
@@ -455,6 +456,10 @@ __global__ __launch_bounds__(256, 2) void tdnn_kernel(const TdnnArgs a) {
     }
     cx.u_tile = __builtin_amdgcn_readfirstlane(utt_of_row(a.out_map, cx.m0));
     cx.off_next = row_off(a.out_map, cx.u_tile + 1);
+    if (POOL) {
+        cx.pool.u = cx.u_tile;
+        cx.pool.end = cx.off_next;
+    }
     set_tile_rows(a, cx);
     cx.tap = 0;
     cx.kc = 0;

@@ -181,6 +181,26 @@ def test_streamed_extraction_from_host_batches(gpu_model, synth):
         list(extract.stream_x_vectors(gpu_model, iter([batches[0].to(DEV)])))
 
 
+def test_path_is_graph_capturable(gpu_model, synth):
+    """xvec_forward neither synchronises nor allocates: torch.cuda.graph captures the whole path and
+    a replay on new input contents reproduces the eager result bit for bit."""
+    x = _gpu(synth.make_mfcc(4, 300, seed=11))
+    eager = gpu_model.extract_x_vec(x)
+    torch.cuda.synchronize()
+    static_x = x.clone()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        static_out = gpu_model.extract_x_vec(static_x)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(static_out, eager)
+    x2 = _gpu(synth.make_mfcc(4, 300, seed=12))
+    static_x.copy_(x2)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(static_out, gpu_model.extract_x_vec(x2))
+
+
 def test_odd_input_width_and_short_utterances(synth):
     """input_size not a multiple of 4 (row padding kernel) and the shortest legal T=15
     (one pooled frame -> NaN std in the reference too)."""

@@ -21,6 +21,15 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// x + (x of lane ^ 32) in every lane: v_permlane32_swap exchanges the upper half of one copy with
+// the lower half of the other in the vector ALU (ds_bpermute would be an LDS round trip plus a
+// wait in the middle of the epilogue)
+__device__ __forceinline__ float add_halves(float x) {
+    const unsigned u = __float_as_uint(x);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 // Pooling cursor of a block: the utterance that holds the first row of the next 32-row group, and
 // the compact row where it ends.  Rows only grow along a block's range, so it advances with a few
 // scalar steps per group instead of a 64-bit division / binary search each time.
@@ -55,7 +64,7 @@ __device__ __forceinline__ void pool_group_impl(const TdnnArgs& a, const f32x16&
 #pragma unroll
         for (int e = 0; e < 16; e += 2) sv += f32x2{v[e], v[e + 1]};
         float s = sv.x + sv.y;
-        s += __shfl_xor(s, 32);
+        s = add_halves(s);
         const float mean = s * (1.f / 32.f);
         const f32x2 mv = {mean, mean};
         f32x2 qv = {0.f, 0.f};
@@ -65,7 +74,7 @@ __device__ __forceinline__ void pool_group_impl(const TdnnArgs& a, const f32x16&
             qv = __builtin_elementwise_fma(d, d, qv);
         }
         float m2 = qv.x + qv.y;
-        m2 += __shfl_xor(m2, 32);
+        m2 = add_halves(m2);
         if (h == 0) {
             float* part = a.pool_part + (grp + pc.u) * (int64_t)(2 * a.ldy);
             part[col] = mean;
@@ -97,8 +106,8 @@ __device__ __forceinline__ void pool_group_impl(const TdnnArgs& a, const f32x16&
             s1 += t;
             s2 = fmaf(t, d, s2);
         }
-        s1 += __shfl_xor(s1, 32);
-        s2 += __shfl_xor(s2, 32);
+        s1 = add_halves(s1);
+        s2 = add_halves(s2);
         const float dm = s1 * (1.f / (float)(hi_l - lo_l));
         const float mean = c + dm;
         const float m2 = fmaxf(s2 - s1 * dm, 0.f);

@@ -134,15 +134,25 @@ __device__ __forceinline__ PoolCur pool_cursor(const TdnnArgs& a, int64_t row) {
     return pc;
 }
 
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc_n(const void* p, int num_bytes) {
     // uniform by construction (kernel argument + blockIdx-derived offset); readfirstlane makes
     // that provable so hipcc emits no waterfall loop around the buffer loads
     const unsigned long long v = reinterpret_cast<unsigned long long>(p);
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
     const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
     void* q = reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo);
-    return __builtin_amdgcn_make_buffer_rsrc(q, (short)0, 0x7fffffff, 0x00020000);
+    return __builtin_amdgcn_make_buffer_rsrc(q, (short)0, __builtin_amdgcn_readfirstlane(num_bytes), 0x00020000);
 }
 
+// descriptor without a range limit (the buffers behind it are padded for every over-read)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) { return make_rsrc_n(p, 0x7fffffff); }
+
+// descriptor of base + off that ends where the buffer of `total` bytes ends: the hardware range
+// check then returns zeros for every byte past the end, with no instruction spent on it
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc_bounded(const void* base, int64_t off, int64_t total) {
+    int64_t left = total - off;
+    left = left < 0 ? 0 : (left > 0x7fffffff ? 0x7fffffff : left);
+    return make_rsrc_n(static_cast<const char*>(base) + off, (int)left);
+}
 
 }  // namespace xvec

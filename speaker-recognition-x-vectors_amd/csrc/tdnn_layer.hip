@@ -138,6 +138,16 @@ __device__ __forceinline__ void set_tile_rows(const TdnnArgs& a, Ctx& cx) {
 // <=4 row groups), so a tile's first chunks are already in flight / in LDS when its MFMAs start
 // and only the first tile of a block pays a prologue.  Past the block's last chunk it stays put
 // (the look-ahead of the final chunks re-reads that chunk; the data is never used).
+// Activation descriptor of the tile at row cx.m0.  GUARD (first layer): X is the caller's tensor,
+// not a padded workspace buffer, so the descriptor ends with it and rows past the end read as 0.
+template <bool GUARD>
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t x_rsrc(const TdnnArgs& a, const Ctx& cx) {
+    const int64_t off = cx.m0 * (int64_t)a.ldx * cx.es;
+    if (GUARD) return make_rsrc_bounded(a.X, off, a.x_rows * (int64_t)a.ldx * cx.es);
+    return make_rsrc(static_cast<const char*>(a.X) + off);
+}
+
+template <bool GUARD>
 __device__ __forceinline__ void advance(const TdnnArgs& a, Ctx& cx, int n_chunks) {
     if (cx.itl + 1 < n_chunks) {
         // taps innermost: consecutive chunks re-read the same 128-byte slab of activation rows,
@@ -153,7 +163,7 @@ __device__ __forceinline__ void advance(const TdnnArgs& a, Ctx& cx, int n_chunks
         if (g_next < cx.g_end) {
             cx.g_s = g_next;
             cx.m0 = g_next * 32;
-            cx.xrsrc = make_rsrc(static_cast<const char*>(a.X) + cx.m0 * (int64_t)a.ldx * cx.es);
+            cx.xrsrc = x_rsrc<GUARD>(a, cx);
             set_tile_rows(a, cx);
             cx.itl = 0;
             cx.kc = 0;
@@ -186,10 +196,10 @@ __device__ __forceinline__ void advance(const TdnnArgs& a, Ctx& cx, int n_chunks
         const int row_shift = cx.tap * a.tap_rows;                                                        \
         const int soff = ((row_shift + 32 * i_) * a.ldx + cx.kc * BKE) * ES;                              \
         if (GUARD) {                                                                                      \
-            const bool ok = (cx.m0 + r0 + 32 * i_ + cx.ur##i_ + row_shift < a.x_rows) &&                  \
-                            (cx.kc * BKE + c * (16 / ES) < a.kpt);                                        \
-            const float4 t = buf_load16(cx.xrsrc, ok ? cx.xo##i_ : 0, ok ? soff : 0);                     \
-            rg.sA##i_##_##n_ = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);                                     \
+            /* K past the layer's width (the folded taps of the next frame): an offset the descriptor's   \
+               range check rejects, so the piece reads as zeros; rows past the tensor: same check */      \
+            const int voff = (cx.kc * BKE + c * (16 / ES) < a.kpt) ? cx.xo##i_ : 0x7ffffff0;              \
+            rg.sA##i_##_##n_ = buf_load16(cx.xrsrc, voff, soff);                                             \
         } else {                                                                                          \
             rg.sA##i_##_##n_ = buf_load16(cx.xrsrc, cx.xo##i_, soff);                                        \
         }                                                                                                 \
@@ -251,7 +261,7 @@ __device__ __forceinline__ void advance(const TdnnArgs& a, Ctx& cx, int n_chunks
               XV_FRG_A(3, 1, 1, S), XV_FRG_B(1, 1, S),                                                    \
               XV_LST_A(0, N_), XV_LST_A(1, N_), XV_LST_A(2, N_), XV_LST_A(3, N_),                         \
               XV_LST_B(0, N_), XV_LST_B(1, N_), XV_LST_B(2, N_), XV_LST_B(3, N_),                         \
-              XV_GLB(3, N_, (IT_) + 1), XV_NOP, advance(a, cx, n_chunks);)                                \
+              XV_GLB(3, N_, (IT_) + 1), XV_NOP, advance<GUARD>(a, cx, n_chunks);)                                \
         XV_KG(1, P_, 1, XV_FRG_A(0, 2, 0, S), XV_FRG_A(1, 2, 0, S), XV_FRG_A(2, 2, 0, S),                 \
               XV_FRG_A(3, 2, 0, S), XV_FRG_B(2, 0, S),                                                    \
               XV_GLD_A(0, N_), XV_GLD_A(1, N_), XV_GLD_A(2, N_), XV_GLD_A(3, N_),                         \
@@ -288,14 +298,14 @@ __device__ __forceinline__ void block_prologue(const TdnnArgs& a, float* smem, C
                                                int n_chunks) {
     constexpr int G = 4;   // fetch all four row groups: rows past a short first tile are allocated
     constexpr int ES = INBF ? 2 : 4, BKE = 128 / ES;
-    const int h = ln.h, sw = ln.sw, a_rd = ln.a_rd, b_rd = ln.b_rd, st_off = ln.st_off, r0 = ln.r0, c = ln.c;
+    const int h = ln.h, sw = ln.sw, a_rd = ln.a_rd, b_rd = ln.b_rd, st_off = ln.st_off, c = ln.c;
     XV_GLD_ALL(0)
-    advance(a, cx, n_chunks);
+    advance<GUARD>(a, cx, n_chunks);
     XV_GLD_ALL(1)
     SB();
     XV_LST_ALL(0)
     SB();
-    advance(a, cx, n_chunks);
+    advance<GUARD>(a, cx, n_chunks);
     XV_GLD_ALL(0)
     __syncthreads();
     XV_FRG_A(0, 0, 0, smem) XV_FRG_A(1, 0, 0, smem) XV_FRG_A(2, 0, 0, smem) XV_FRG_A(3, 0, 0, smem)
@@ -311,7 +321,7 @@ template <int G, bool GUARD, bool POOL, bool STORE, bool INBF, bool OUTBF>
 __device__ __forceinline__ void process_tile(const TdnnArgs& a, float* smem, Ctx& cx, Regs& rg, const Lane& ln,
                                              int64_t g0, int n0, int n_chunks) {
     constexpr int ES = INBF ? 2 : 4, BKE = 128 / ES;
-    const int h = ln.h, sw = ln.sw, a_rd = ln.a_rd, b_rd = ln.b_rd, st_off = ln.st_off, r0 = ln.r0, c = ln.c;
+    const int h = ln.h, sw = ln.sw, a_rd = ln.a_rd, b_rd = ln.b_rd, st_off = ln.st_off, c = ln.c;
     f32x16 acc0, acc1, acc2, acc3;
 #pragma unroll
     for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; acc2[e] = 0.f; acc3[e] = 0.f; }
@@ -444,7 +454,7 @@ __global__ __launch_bounds__(256, 2) void tdnn_kernel(const TdnnArgs a) {
     cx.m0 = g_begin * 32;
     constexpr int ES = INBF ? 2 : 4;
     cx.es = ES;
-    cx.xrsrc = make_rsrc(static_cast<const char*>(a.X) + cx.m0 * (int64_t)a.ldx * ES);
+    cx.xrsrc = x_rsrc<GUARD>(a, cx);
     cx.wrsrc = make_rsrc(static_cast<const char*>(a.W) + (int64_t)n0 * a.k_pad * ES);
     cx.x_base = ln.r0 * a.ldx * ES + ln.c * 16;
     cx.w_toff = ln.r0 * a.k_pad * ES + ln.c * 16;
@@ -488,18 +498,14 @@ template <bool GUARD, bool POOL, bool STORE, bool INBF, bool OUTBF>
 static hipError_t launch_variant(const TdnnArgs& a, hipStream_t s) {
     auto kern = tdnn_kernel<GUARD, POOL, STORE, INBF, OUTBF>;
     static bool attr_set = false;   // per-variant; benign if raced (idempotent)
-    static int lds_pad = 0;
     if (!attr_set) {
-        const char* e_pad = getenv("XVEC_LDS_PAD");   // experiment knob: extra LDS to cap blocks/CU
-        lds_pad = e_pad ? atoi(e_pad) : 0;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes + lds_pad);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     const int grid = a.blocks_per_col * a.n_tiles;
-    const int lds_bytes = kLdsBytes + lds_pad;
-    kern<<<dim3(grid), dim3(256), lds_bytes, s>>>(a);
+    kern<<<dim3(grid), dim3(256), kLdsBytes, s>>>(a);
     return hipGetLastError();
 }
 

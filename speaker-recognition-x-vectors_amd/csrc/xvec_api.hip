@@ -182,7 +182,7 @@ int run_tdnn(xvec_handle* h, int layer, TdnnVariant v, const void* X, int ldx, i
         // CU-pair-aware range sizes need the full 2-blocks-per-CU grid and whole XCD runs per half
         const int nwg = a.blocks_per_col * a.n_tiles;
         const bool ok = h->blocks_per_cu == 2 && nwg == 2 * h->num_cu && nwg % 16 == 0 &&
-                        (nwg / 8) % (2 * a.n_tiles) == 0 && !getenv("XVEC_NO_PAIR_BALANCE");
+                        (nwg / 8) % (2 * a.n_tiles) == 0;
         a.pair_period = ok ? (nwg / 8) / a.n_tiles : 0;
     }
     a.pool_part = part;
@@ -342,7 +342,7 @@ int xvec_create(const xvec_cfg* cfg, xvec_handle** out) {
     h->cfg = *cfg;
     h->num_cu = prop.multiProcessorCount;
     {
-        const char* e = getenv("XVEC_BLOCKS_PER_CU");   // experiment knob
+        const char* e = getenv("XVEC_BLOCKS_PER_CU");   // diagnostic knob (profiles/ab_env.sh); 2 = what the LDS allows
         h->blocks_per_cu = e ? atoi(e) : 2;
         if (h->blocks_per_cu < 1) h->blocks_per_cu = 1;
     }

@@ -1,0 +1,24 @@
+#!/bin/bash
+# Counters of the MFCC kernel (profiles/diag/mfcc_timing.py): bash profiles/run_pmc_mfcc.sh <tag>
+tag=${1:-mfcc}
+cd /tmp && export TMPDIR=/tmp
+cd "$GRAFT_REPO_ROOT"
+out=gpurun_out/pmc_$tag
+mkdir -p $out
+i=0
+for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE" \
+           "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU GRBM_GUI_ACTIVE"; do
+  i=$((i+1))
+  rocprofv3 --pmc $grp --output-format csv -d $out/p$i -o p$i -- python3 profiles/diag/mfcc_timing.py > $out/p$i.log 2>&1
+  echo "pass $i: exit $?"
+done
+python3 - <<PY
+import csv, glob, collections
+agg = collections.defaultdict(list)
+for f in glob.glob("$out/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "mfcc_kernel" in r["Kernel_Name"]:
+            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k in sorted(agg):
+    print(f"{k:28s} {sum(agg[k]) / len(agg[k]):16.1f}  n={len(agg[k])}")
+PY

@@ -29,7 +29,7 @@ constexpr float kEps = 2.220446049250313e-16f;   // numpy.finfo(float).eps, what
 
 struct MfccDev {
     // one table blob, copied into LDS by every block:
-    //   twiddle[nfft] (cos, -sin pairs) | dctl[numcep*nfilt] | fb_w[fb_nnz] | fb_lo[nfilt] | fb_off[nfilt+1]
+    //   twiddles per pass (cos, -sin pairs) | dctl[numcep][nfilt|1] | fb_w[fb_nnz] | fb_lo[nfilt] | fb_off[nfilt+1]
     const float* tables;
     int tw_off, dctl_off, fbw_off, fblo_off, fboff_off, table_floats;
     int frame_len, frame_step, nfft, log2n, nbins, nfilt, numcep, append_energy;
@@ -37,6 +37,13 @@ struct MfccDev {
 };
 
 __device__ __forceinline__ unsigned bitrev(unsigned v, int bits) { return __brev(v) >> (32 - bits); }
+
+// LDS position of complex point i: one pad slot per 32 points.  Power-of-two strides (the
+// bit-reversed store, the butterflies of the first stages) otherwise land on a handful of banks:
+// rocprofv3 counted 53 % of all LDS cycles as bank conflicts without it.
+__host__ __device__ constexpr int zpos(int i) { return i + (i >> 5); }
+// floats per wave: padded complex image + two power spectra
+__host__ __device__ constexpr int wave_floats(int nfft, int nbins) { return 2 * zpos(nfft) + 2 * ((nbins + 1) & ~1); }
 
 // order this wave's LDS traffic: earlier ds_writes are complete and visible to the wave's later
 // ds_reads (one wave owns its LDS region, so no block barrier is ever needed)
@@ -50,8 +57,8 @@ constexpr int kWavesPerBlock = kThreads / 64;
 // One WAVE per PAIR of frames (eight frames per 256-thread block).  The block first copies the
 // small tables (twiddles, DCT x lifter rows, the non-zero filterbank weights) into LDS.  Each wave
 // then packs its two real frames into ONE complex signal (frame A real part, frame B imaginary
-// part), runs a single radix-2 FFT on the interleaved image in its private LDS region (8-byte
-// ds_read/ds_write, four butterflies per lane and stage, no block barriers) and separates the two
+// part), runs a single FFT on the image in its private, padded LDS region (8-byte ds_read/ds_write,
+// two radix-2 stages per pass, no block barriers) and separates the two
 // spectra by conjugate symmetry.  Lanes 0-31 finish frame A, lanes 32-63 frame B: mel filters
 // (one lane per filter walks its short run of bins), log, DCT x lifter rows, store.
 __global__ __launch_bounds__(kThreads) void mfcc_kernel(const float* __restrict__ sig, int64_t n_samples,
@@ -68,9 +75,9 @@ __global__ __launch_bounds__(kThreads) void mfcc_kernel(const float* __restrict_
     const int* fb_off = reinterpret_cast<const int*>(tab + d.fboff_off);
 
     const int nb_pad = (d.nbins + 1) & ~1;
-    const int per_wave = 2 * d.nfft + 2 * nb_pad;             // floats: complex image + two power spectra
+    const int per_wave = wave_floats(d.nfft, d.nbins);
     float2* z = reinterpret_cast<float2*>(lds + d.table_floats + (size_t)wave * per_wave);
-    float* work = reinterpret_cast<float*>(z + d.nfft);       // [2][nb_pad] power spectra of frames A, B
+    float* work = reinterpret_cast<float*>(z + zpos(d.nfft));   // [2][nb_pad] power spectra of frames A, B
 
     const int fa = 2 * (blockIdx.x * kWavesPerBlock + wave), b = blockIdx.y;
     if (fa >= n_frames) return;                               // whole wave leaves together (no later block barrier)
@@ -87,21 +94,50 @@ __global__ __launch_bounds__(kThreads) void mfcc_kernel(const float* __restrict_
             if (ga < n_samples) va = (ga == 0) ? s[0] : s[ga] - d.preemph * s[ga - 1];
             if (has_b && gb < n_samples) vb = s[gb] - d.preemph * s[gb - 1];
         }
-        z[bitrev((unsigned)n, d.log2n)] = make_float2(va, vb);
+        z[zpos((int)bitrev((unsigned)n, d.log2n))] = make_float2(va, vb);
     }
     wave_lds_sync();
 
-    // ---- radix-2 decimation-in-time FFT
-    for (int st = 0; st < d.log2n; ++st) {
-        const int half = 1 << st;
-        for (int i = lane; i < d.nfft / 2; i += 64) {
-            const int j = i & (half - 1);
-            const int lo = ((i >> st) << (st + 1)) + j, hi = lo + half;
-            const float2 w = tw2[j << (d.log2n - 1 - st)];
-            const float2 x = z[hi], u = z[lo];
+    // ---- decimation-in-time FFT on the bit-reversed image, two radix-2 stages per pass: the four
+    // points {p, p+h, p+2h, p+3h} (h = 4^pass, bits of weight h and 2h clear in p) form a closed
+    // two-stage butterfly, so a pass touches every point once instead of twice.  The twiddles of a
+    // pass are stored contiguously per j, {W_2h^j, W_4h^j, W_4h^(j+h)}: consecutive lanes read
+    // consecutive 24-byte records (strided reads of one N/2-entry table were up to 16-way conflicts).
+    const float2* twp = tw2;
+    int st = 0;
+    for (; st + 1 < d.log2n; st += 2) {
+        const int h = 1 << st;
+        for (int i = lane; i < d.nfft / 4; i += 64) {
+            const int j = i & (h - 1);
+            const int p0 = ((i >> st) << (st + 2)) + j;
+            const float2 w1 = twp[3 * j], w2 = twp[3 * j + 1], w3 = twp[3 * j + 2];
+            const int q0 = zpos(p0), q1 = zpos(p0 + h), q2 = zpos(p0 + 2 * h), q3 = zpos(p0 + 3 * h);
+            const float2 a0 = z[q0], a1 = z[q1], a2 = z[q2], a3 = z[q3];
+            // first stage: (a0, a1) and (a2, a3) with W_2h^j
+            const float t1r = a1.x * w1.x - a1.y * w1.y, t1i = a1.x * w1.y + a1.y * w1.x;
+            const float t3r = a3.x * w1.x - a3.y * w1.y, t3i = a3.x * w1.y + a3.y * w1.x;
+            const float b0r = a0.x + t1r, b0i = a0.y + t1i, b1r = a0.x - t1r, b1i = a0.y - t1i;
+            const float b2r = a2.x + t3r, b2i = a2.y + t3i, b3r = a2.x - t3r, b3i = a2.y - t3i;
+            // second stage: (b0, b2) with W_4h^j and (b1, b3) with W_4h^(j+h)
+            const float u2r = b2r * w2.x - b2i * w2.y, u2i = b2r * w2.y + b2i * w2.x;
+            const float u3r = b3r * w3.x - b3i * w3.y, u3i = b3r * w3.y + b3i * w3.x;
+            z[q0] = make_float2(b0r + u2r, b0i + u2i);
+            z[q2] = make_float2(b0r - u2r, b0i - u2i);
+            z[q1] = make_float2(b1r + u3r, b1i + u3i);
+            z[q3] = make_float2(b1r - u3r, b1i - u3i);
+        }
+        twp += 3 * h;
+        wave_lds_sync();
+    }
+    if (st < d.log2n) {                                                // odd log2(nfft): one plain stage, W_N^j
+        const int half = d.nfft >> 1;
+        for (int i = lane; i < half; i += 64) {
+            const float2 w = twp[i];
+            const int ql = zpos(i), qh = zpos(i + half);
+            const float2 x = z[qh], u = z[ql];
             const float tr = x.x * w.x - x.y * w.y, ti = x.x * w.y + x.y * w.x;
-            z[lo] = make_float2(u.x + tr, u.y + ti);
-            z[hi] = make_float2(u.x - tr, u.y - ti);
+            z[ql] = make_float2(u.x + tr, u.y + ti);
+            z[qh] = make_float2(u.x - tr, u.y - ti);
         }
         wave_lds_sync();
     }
@@ -110,7 +146,7 @@ __global__ __launch_bounds__(kThreads) void mfcc_kernel(const float* __restrict_
     float ea = 0.f, eb = 0.f;
     const float scale = 0.25f / (float)d.nfft;                // (1/2)^2 from the split, 1/nfft from powspec
     for (int k = lane; k < d.nbins; k += 64) {
-        const float2 p = z[k], q = z[(d.nfft - k) & (d.nfft - 1)];
+        const float2 p = z[zpos(k)], q = z[zpos((d.nfft - k) & (d.nfft - 1))];
         const float ar = p.x + q.x, ai = p.y - q.y, br = p.y + q.y, bi = q.x - p.x;
         const float pa = (ar * ar + ai * ai) * scale, pb = (br * br + bi * bi) * scale;
         work[k] = pa;
@@ -144,7 +180,7 @@ __global__ __launch_bounds__(kThreads) void mfcc_kernel(const float* __restrict_
     const int f = fa + sel;
     if (f < n_frames) {
         for (int c = lane & 31; c < d.numcep; c += 32) {
-            const float* row = dctl + c * d.nfilt;
+            const float* row = dctl + c * (d.nfilt | 1);       // odd row stride: lanes hit distinct banks
             float v = 0.f;
             for (int j = 0; j < d.nfilt; ++j) v = fmaf(le[j], row[j], v);
             if (c == 0 && d.append_energy) v = logf(energy);
@@ -210,18 +246,32 @@ int xvec_mfcc_create(const xvec_mfcc_cfg* cfg, xvec_mfcc_plan** out) {
     }
     off[nfilt] = (int)fbw.size();
     // scipy dct(type=2, norm='ortho') rows times base.lifter
-    std::vector<float> dctl((size_t)numcep * nfilt);
+    const int dct_ld = nfilt | 1;
+    std::vector<float> dctl((size_t)numcep * dct_ld, 0.f);
     for (int k = 0; k < numcep; ++k) {
         const double scale = std::sqrt((k == 0 ? 1.0 : 2.0) / nfilt);
         const double lift = cfg->ceplifter > 0 ? 1.0 + (cfg->ceplifter / 2.0) * std::sin(M_PI * k / cfg->ceplifter) : 1.0;
         for (int m = 0; m < nfilt; ++m)
-            dctl[(size_t)k * nfilt + m] = (float)(std::cos(M_PI * k * (2 * m + 1) / (2.0 * nfilt)) * scale * lift);
+            dctl[(size_t)k * dct_ld + m] = (float)(std::cos(M_PI * k * (2 * m + 1) / (2.0 * nfilt)) * scale * lift);
     }
-    std::vector<float> tw(nfft);
-    for (int i = 0; i < nfft / 2; ++i) {
-        tw[2 * i] = (float)std::cos(2.0 * M_PI * i / nfft);
-        tw[2 * i + 1] = (float)(-std::sin(2.0 * M_PI * i / nfft));
+    // twiddles W_M^j = exp(-2 pi i j / M), grouped per pass of the kernel: for h = 1, 4, 16, ...
+    // records {W_2h^j, W_4h^j, W_4h^(j+h)}, j < h; then, for odd log2(nfft), W_N^j, j < N/2
+    std::vector<float> tw;
+    auto push_w = [&](int j, int M) {
+        tw.push_back((float)std::cos(2.0 * M_PI * j / M));
+        tw.push_back((float)(-std::sin(2.0 * M_PI * j / M)));
+    };
+    int st = 0;
+    for (; st + 1 < log2n; st += 2) {
+        const int h = 1 << st;
+        for (int j = 0; j < h; ++j) {
+            push_w(j, 2 * h);
+            push_w(j, 4 * h);
+            push_w(j + h, 4 * h);
+        }
     }
+    if (st < log2n)
+        for (int j = 0; j < nfft / 2; ++j) push_w(j, nfft);
 
     xvec_mfcc_plan* p = new (std::nothrow) xvec_mfcc_plan();
     if (!p) return mfail(XVEC_ERR_STATE, "out of host memory");
@@ -281,7 +331,7 @@ int xvec_mfcc(xvec_mfcc_plan* p, const float* signal, int32_t B, int64_t n_sampl
     if (!p || !signal || !out) return mfail(XVEC_ERR_ARG, "null argument");
     if (B < 1 || B > 65535 || n_samples < 1) return mfail(XVEC_ERR_ARG, "need 1 <= B <= 65535 and n_samples >= 1");
     const int n_frames = xvec_mfcc_frames(p, n_samples);
-    const int per_wave = 2 * p->dev.nfft + 2 * ((p->dev.nbins + 1) & ~1);
+    const int per_wave = wave_floats(p->dev.nfft, p->dev.nbins);
     const size_t lds = ((size_t)per_wave * kWavesPerBlock + p->dev.table_floats) * 4;
     if (lds > 64 * 1024) {   // nfft 4096: opt in to the larger dynamic LDS once
         static bool attr = false;

@@ -61,8 +61,14 @@ constexpr int kWavesPerBlock = kThreads / 64;
 // two radix-2 stages per pass, no block barriers) and separates the two
 // spectra by conjugate symmetry.  Lanes 0-31 finish frame A, lanes 32-63 frame B: mel filters
 // (one lane per filter walks its short run of bins), log, DCT x lifter rows, store.
+// L2N: log2(nfft) fixed at compile time (9: the reference's nfft = 512), or 0 = taken from `d`.  With
+// constant trip counts the sample loads of a frame, the two butterfly groups of a pass and the
+// bins of the split are issued together instead of one LDS / memory round trip at a time.
+template <int L2N>
 __global__ __launch_bounds__(kThreads) void mfcc_kernel(const float* __restrict__ sig, int64_t n_samples,
                                                         int n_frames, MfccDev d, float* __restrict__ out) {
+    const int log2n = L2N ? L2N : d.log2n;
+    const int nfft = L2N ? (1 << L2N) : d.nfft;
     extern __shared__ float lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float* tab = lds;
@@ -75,26 +81,27 @@ __global__ __launch_bounds__(kThreads) void mfcc_kernel(const float* __restrict_
     const int* fb_off = reinterpret_cast<const int*>(tab + d.fboff_off);
 
     const int nb_pad = (d.nbins + 1) & ~1;
-    const int per_wave = wave_floats(d.nfft, d.nbins);
+    const int per_wave = wave_floats(nfft, d.nbins);
     float2* z = reinterpret_cast<float2*>(lds + d.table_floats + (size_t)wave * per_wave);
-    float* work = reinterpret_cast<float*>(z + zpos(d.nfft));   // [2][nb_pad] power spectra of frames A, B
+    float* work = reinterpret_cast<float*>(z + zpos(nfft));   // [2][nb_pad] power spectra of frames A, B
 
     const int fa = 2 * (blockIdx.x * kWavesPerBlock + wave), b = blockIdx.y;
     if (fa >= n_frames) return;                               // whole wave leaves together (no later block barrier)
     const bool has_b = fa + 1 < n_frames;
     const float* s = sig + (int64_t)b * n_samples;
     const int64_t start = (int64_t)fa * d.frame_step;
-    const int used = d.frame_len < d.nfft ? d.frame_len : d.nfft;   // rfft(frame, nfft) truncates long frames
+    const int used = d.frame_len < nfft ? d.frame_len : nfft;   // rfft(frame, nfft) truncates long frames
 
     // ---- the two pre-emphasised frames, zero padded to nfft, as one complex signal in bit-reversed order
-    for (int n = lane; n < d.nfft; n += 64) {
+#pragma unroll
+    for (int n = lane; n < nfft; n += 64) {
         float va = 0.f, vb = 0.f;
         if (n < used) {
             const int64_t ga = start + n, gb = ga + d.frame_step;
             if (ga < n_samples) va = (ga == 0) ? s[0] : s[ga] - d.preemph * s[ga - 1];
             if (has_b && gb < n_samples) vb = s[gb] - d.preemph * s[gb - 1];
         }
-        z[zpos((int)bitrev((unsigned)n, d.log2n))] = make_float2(va, vb);
+        z[zpos((int)bitrev((unsigned)n, log2n))] = make_float2(va, vb);
     }
     wave_lds_sync();
 
@@ -105,9 +112,10 @@ __global__ __launch_bounds__(kThreads) void mfcc_kernel(const float* __restrict_
     // consecutive 24-byte records (strided reads of one N/2-entry table were up to 16-way conflicts).
     const float2* twp = tw2;
     int st = 0;
-    for (; st + 1 < d.log2n; st += 2) {
+    for (; st + 1 < log2n; st += 2) {
         const int h = 1 << st;
-        for (int i = lane; i < d.nfft / 4; i += 64) {
+#pragma unroll
+        for (int i = lane; i < nfft / 4; i += 64) {
             const int j = i & (h - 1);
             const int p0 = ((i >> st) << (st + 2)) + j;
             const float2 w1 = twp[3 * j], w2 = twp[3 * j + 1], w3 = twp[3 * j + 2];
@@ -129,8 +137,9 @@ __global__ __launch_bounds__(kThreads) void mfcc_kernel(const float* __restrict_
         twp += 3 * h;
         wave_lds_sync();
     }
-    if (st < d.log2n) {                                                // odd log2(nfft): one plain stage, W_N^j
-        const int half = d.nfft >> 1;
+    if (st < log2n) {                                                // odd log2(nfft): one plain stage, W_N^j
+        const int half = nfft >> 1;
+#pragma unroll
         for (int i = lane; i < half; i += 64) {
             const float2 w = twp[i];
             const int ql = zpos(i), qh = zpos(i + half);
@@ -144,9 +153,9 @@ __global__ __launch_bounds__(kThreads) void mfcc_kernel(const float* __restrict_
 
     // ---- split the spectra (A = (Z[k] + conj Z[N-k])/2, B = (Z[k] - conj Z[N-k])/(2i)), power, energies
     float ea = 0.f, eb = 0.f;
-    const float scale = 0.25f / (float)d.nfft;                // (1/2)^2 from the split, 1/nfft from powspec
+    const float scale = 0.25f / (float)nfft;                // (1/2)^2 from the split, 1/nfft from powspec
     for (int k = lane; k < d.nbins; k += 64) {
-        const float2 p = z[zpos(k)], q = z[zpos((d.nfft - k) & (d.nfft - 1))];
+        const float2 p = z[zpos(k)], q = z[zpos((nfft - k) & (nfft - 1))];
         const float ar = p.x + q.x, ai = p.y - q.y, br = p.y + q.y, bi = q.x - p.x;
         const float pa = (ar * ar + ai * ai) * scale, pb = (br * br + bi * bi) * scale;
         work[k] = pa;
@@ -336,15 +345,19 @@ int xvec_mfcc(xvec_mfcc_plan* p, const float* signal, int32_t B, int64_t n_sampl
     if (lds > 64 * 1024) {   // nfft 4096: opt in to the larger dynamic LDS once
         static bool attr = false;
         if (!attr) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(mfcc_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(mfcc_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     160 * 1024) != hipSuccess)
                 return mfail(XVEC_ERR_HIP, "hipFuncSetAttribute failed");
             attr = true;
         }
     }
     const int grid_x = (n_frames + 2 * kWavesPerBlock - 1) / (2 * kWavesPerBlock);
-    mfcc_kernel<<<dim3(grid_x, B), kThreads, lds, static_cast<hipStream_t>(stream)>>>(signal, n_samples, n_frames,
-                                                                                    p->dev, out);
+    if (p->dev.log2n == 9)
+        mfcc_kernel<9><<<dim3(grid_x, B), kThreads, lds, static_cast<hipStream_t>(stream)>>>(signal, n_samples, n_frames,
+                                                                                           p->dev, out);
+    else
+        mfcc_kernel<0><<<dim3(grid_x, B), kThreads, lds, static_cast<hipStream_t>(stream)>>>(signal, n_samples, n_frames,
+                                                                                           p->dev, out);
     if (hipGetLastError() != hipSuccess) return mfail(XVEC_ERR_HIP, "mfcc kernel launch failed");
     return XVEC_OK;
 }

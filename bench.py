@@ -65,11 +65,12 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU-baseline work (0 = skip)")
     ap.add_argument("--dtype", choices=("fp32", "bf16"), default="fp32",
                     help="frame-level arithmetic; the headline (BASELINE configs[1]) is fp32")
-    ap.add_argument("--workload", choices=("fixed", "ragged", "job"), default="fixed",
+    ap.add_argument("--workload", choices=("fixed", "ragged", "job", "wave"), default="fixed",
                     help="fixed: configs[1] (the bench line).  ragged: configs[2], one batch of utterances of "
                          "200-1000 frames, zero-padded with a lengths mask.  job: configs[3], --utterances "
                          "fixed-length utterances generated on the device batch by batch, sharded over the ranks, "
-                         "one all-gather at the end (--steps is derived)")
+                         "one all-gather at the end (--steps is derived).  wave: 3 s waveforms at 16 kHz in HBM -> "
+                         "MFCC front end (next row N3) -> the path (299 frames), one step = one batch")
     ap.add_argument("--utterances", type=int, default=100_000, help="job size of --workload job")
     args = ap.parse_args()
 
@@ -96,6 +97,8 @@ def main():
         lens_np = xa.synth.make_lengths(B)                  # default_rng(1234).integers(200, 1001, B)  
         lengths = lens_np.tolist()
         T = int(lens_np.max())
+    elif args.workload == "wave":
+        T = 299                                             # frames of a 3 s crop (reference dataset.py:124-135)
     elif args.workload == "job":
         lo, hi = xa.extract.shard_bounds(args.utterances, rank, world)
         n_local = hi - lo
@@ -111,8 +114,17 @@ def main():
     emb = torch.empty((K * B, 512), device=dev, dtype=torch.float32) if n_local is None else None
     gathered = torch.empty((world * K * B, 512), device=dev, dtype=torch.float32) if world > 1 and n_local is None else None
 
+    waves = fe = None
+    if args.workload == "wave":
+        waves = 0.1 * torch.randn((B, 48000), generator=gen, device=dev, dtype=torch.float32)
+        fe = xa.MfccFrontEnd(device=dev)
+        assert fe(waves).shape == (B, T, 24)
+
     def step(k):
-        emb[k * B:(k + 1) * B] = model.extract_x_vec(x, lengths=lengths)
+        if waves is not None:
+            emb[k * B:(k + 1) * B] = model.extract_x_vec(fe(waves))
+        else:
+            emb[k * B:(k + 1) * B] = model.extract_x_vec(x, lengths=lengths)
 
     def job():
         # the product's sharded job (extract.extract_sharded): contiguous utterance block per rank,
@@ -233,6 +245,8 @@ def main():
                                     f"utterances, {args.dtype} frame-level stack, ",
                            "ragged": f"configs[2]: batch={B} utterances of 200-1000 frames (numpy default_rng(1234)), zero-padded "
                                      f"to {T} with a lengths mask, {args.dtype}, ",
+                           "wave": f"next row N3 + path: batch={B} waveforms of 48000 samples (3 s, 16 kHz) in HBM -> MFCC "
+                                   f"kernel -> {T} frames x 24 -> {args.dtype} frame-level stack, ",
                            "job": f"configs[3]: {args.utterances} utterances of {T} frames generated on the device batch by "
                                   f"batch ({B}), sharded over {world} rank(s), {args.dtype}, "}[args.workload]
                                    + "extract_x_vec layer 6, random-init weights seed 42",

@@ -20,6 +20,10 @@
 //     register sets, so a chunk's global loads are issued ~1.5 chunks before they are
 //     stored), one block barrier per chunk.  LDS rows are 128 B with a 16-B-chunk XOR
 //     swizzle: the ds_read_b128 fragment reads are bank-conflict free.
+//   * the chunks of a tile are walked with the taps innermost (chunk kc of tap 0, 1, 2, then kc+1;
+//     pack.hip stores the weights' K axis in that order): the dilated taps re-read a 128-byte slab
+//     of activation rows while it is still in L2.  bf16: the weights are packed fragment-major and
+//     go from global memory straight into the MFMA B operand, only activations pass through LDS.
 //   * each ds_read_b128 feeds four MFMAs: lane half h owns k = 8q+4h..8q+4h+3 of every
 //     8-wide k group, for A and B alike, so the products pair up (the k order inside a chunk
 //     is permuted, which fp32 addition tolerates to rounding).

@@ -26,11 +26,13 @@ __device__ __forceinline__ float4 ld4(const float* row, int k, int K) {
 
 constexpr int kAffWaves = 8;
 
-#define AFF_MFMA4(a_, b_)                                                      \
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_.x, b_.x, acc, 0, 0, 0);      \
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_.y, b_.y, acc, 0, 0, 0);      \
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_.z, b_.z, acc, 0, 0, 0);      \
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_.w, b_.w, acc, 0, 0, 0);
+// four k-pairs of one 16-byte operand pair; two accumulators alternate so consecutive MFMAs do
+// not wait on each other's result
+#define AFF_MFMA4(a_, b_)                                                        \
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_.x, b_.x, acc0, 0, 0, 0);      \
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_.y, b_.y, acc1, 0, 0, 0);      \
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_.z, b_.z, acc0, 0, 0, 0);      \
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_.w, b_.w, acc1, 0, 0, 0);
 
 template <bool VEC>
 __global__ __launch_bounds__(64 * kAffWaves) void affine_f32_kernel(const float* __restrict__ x,
@@ -46,28 +48,35 @@ __global__ __launch_bounds__(64 * kAffWaves) void affine_f32_kernel(const float*
     const float* xa = x + (int64_t)m * K;
     const float* wb = W + (int64_t)n * K;
 
-    f32x16 acc;
+    f32x16 acc0, acc1;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
 
     // lane half h owns k = 8g+4h .. 8g+4h+3 of k-group g (for A and B alike); the block's waves
-    // take interleaved k-groups, four per trip so eight 16-byte loads per lane are in flight
+    // take interleaved k-groups, four per trip (ld4 returns zeros past K).  The loads of trip t+1
+    // are issued before the MFMAs of trip t: with one wave per SIMD nothing else hides the
+    // ~1 us a load takes, and the launch is nothing but such trips (K = 3000: 12 of them).
     const int groups = (K + 7) / 8;
     constexpr int S = kAffWaves;
-    int g = wave;
-    for (; g + 3 * S < groups; g += 4 * S) {
-        const int k0 = 8 * g + 4 * h;
-        const float4 a0 = ld4<VEC>(xa, k0, K), b0 = ld4<VEC>(wb, k0, K);
-        const float4 a1 = ld4<VEC>(xa, k0 + 8 * S, K), b1 = ld4<VEC>(wb, k0 + 8 * S, K);
-        const float4 a2 = ld4<VEC>(xa, k0 + 16 * S, K), b2 = ld4<VEC>(wb, k0 + 16 * S, K);
-        const float4 a3 = ld4<VEC>(xa, k0 + 24 * S, K), b3 = ld4<VEC>(wb, k0 + 24 * S, K);
-        AFF_MFMA4(a0, b0) AFF_MFMA4(a1, b1) AFF_MFMA4(a2, b2) AFF_MFMA4(a3, b3)
+    float4 a0, a1, a2, a3, b0, b1, b2, b3;
+#define AFF_LOAD(g_)                                                                            \
+    {                                                                                           \
+        const int k0 = 8 * (g_) + 4 * h;                                                        \
+        a0 = ld4<VEC>(xa, k0, K); b0 = ld4<VEC>(wb, k0, K);                                     \
+        a1 = ld4<VEC>(xa, k0 + 8 * S, K); b1 = ld4<VEC>(wb, k0 + 8 * S, K);                     \
+        a2 = ld4<VEC>(xa, k0 + 16 * S, K); b2 = ld4<VEC>(wb, k0 + 16 * S, K);                   \
+        a3 = ld4<VEC>(xa, k0 + 24 * S, K); b3 = ld4<VEC>(wb, k0 + 24 * S, K);                   \
     }
-    for (; g < groups; g += S) {
-        const int k0 = 8 * g + 4 * h;
-        const float4 a0 = ld4<VEC>(xa, k0, K), b0 = ld4<VEC>(wb, k0, K);
-        AFF_MFMA4(a0, b0)
+    AFF_LOAD(wave)
+    for (int g = wave; g < groups; g += 4 * S) {
+        const float4 c0 = a0, c1 = a1, c2 = a2, c3 = a3, d0 = b0, d1 = b1, d2 = b2, d3 = b3;
+        if (g + 4 * S < groups) AFF_LOAD(g + 4 * S)
+        AFF_MFMA4(c0, d0) AFF_MFMA4(c1, d1) AFF_MFMA4(c2, d2) AFF_MFMA4(c3, d3)
     }
+#undef AFF_LOAD
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = acc0[e] + acc1[e];
 
     // accumulator element e of lane (r,h): row = (e&3) + 8*(e>>2) + 4*h, col = r
 #pragma unroll

@@ -115,17 +115,34 @@ __global__ __launch_bounds__(256) void pool_finalize_kernel(const PoolFinalizeAr
     if (ch >= a.C) return;
     const int64_t off = row_off(a.map, u), end = row_off(a.map, u + 1);   // pooled rows are [off, end)
     float n = 0.f, mean = 0.f, m2 = 0.f;
-    for (int64_t sub = off / a.sub_rows; sub * a.sub_rows < end; ++sub) {
-        const int64_t lo = sub * a.sub_rows > off ? sub * a.sub_rows : off;
-        const int64_t hi = (sub + 1) * a.sub_rows < end ? (sub + 1) * a.sub_rows : end;
-        if (hi <= lo) continue;
-        const float* p = a.part + (sub + u) * (int64_t)(2 * a.n_pad);
-        const float nb = (float)(hi - lo), mb = p[ch], m2b = p[a.n_pad + ch];
-        const float nn = n + nb;
-        const float delta = mb - mean;
-        mean += delta * (nb / nn);
-        m2 += m2b + delta * delta * (n * nb / nn);
-        n = nn;
+    // four sub-tiles per trip, their eight loads issued before the first merge: the kernel is a chain
+    // of ~10 dependent round trips per thread otherwise (12 us for 31 MB of partials)
+    for (int64_t sub0 = off / a.sub_rows; sub0 * a.sub_rows < end; sub0 += 4) {
+        float nb[4], mb[4], m2b[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t sub = sub0 + j;
+            const int64_t lo = sub * a.sub_rows > off ? sub * a.sub_rows : off;
+            const int64_t hi = (sub + 1) * a.sub_rows < end ? (sub + 1) * a.sub_rows : end;
+            nb[j] = hi > lo ? (float)(hi - lo) : 0.f;
+            mb[j] = 0.f;
+            m2b[j] = 0.f;
+            if (hi > lo) {
+                const float* p = a.part + (sub + u) * (int64_t)(2 * a.n_pad);
+                mb[j] = p[ch];
+                m2b[j] = p[a.n_pad + ch];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (nb[j] > 0.f) {
+                const float nn = n + nb[j];
+                const float delta = mb[j] - mean;
+                mean += delta * (nb[j] / nn);
+                m2 += m2b[j] + delta * delta * (n * nb[j] / nn);
+                n = nn;
+            }
+        }
     }
     float* o = a.out + (int64_t)u * 2 * a.C;
     o[ch] = mean;

@@ -9,6 +9,11 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+# torch first: it ships its own HIP runtime, and libxvec_hip.so must bind to THAT copy.  Loading the
+# library before torch pulls in the system's libamdhip64 as a second runtime in the process, and the
+# later one reports "no ROCm-capable device" (seen with build() followed by smoke() in one process).
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # XVEC_LIB: development override (A/B runs of two builds on one GPU box); the default is the in-tree build
 LIB_PATH = os.environ.get("XVEC_LIB") or os.path.join(_HERE, "libxvec_hip.so")

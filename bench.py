@@ -29,7 +29,8 @@ import torch
 HBM_PEAK = 8.0e12         # B/s, MI355X_MICROARCH.md (spec)
 FP32_MFMA_PEAK = 157.3e12  # FLOP/s dense fp32 MFMA (= fp32 vector peak), MI355X_MICROARCH.md
 BF16_MFMA_PEAK = 2.5e15    # FLOP/s dense bf16 MFMA, MI355X_MICROARCH.md
-BYTES_PER_UTT = 8_238_208  # every layer reads its input once, writes its output once (T=300, fp32)
+BYTES_PER_UTT = 8_238_208  # every layer reads its input once, writes its output once (T=300, fp32);
+                           # bf16 activations halve it (4.12 MB/utt)
 
 
 def layer_flops(T):
@@ -202,18 +203,19 @@ def main():
     avg_ms = {n: acc[n] / min(K, 50) for n in names}
 
     if rank == 0:
+        act_bytes_scale = 0.5 if args.dtype == "bf16" else 1.0
         if lengths is None:
             lf = [f * B for f in layer_flops(T)]
             n_done = world * K * B if n_local is None else args.utterances
             frames_done = n_done * T
-            path_flops, path_bytes = total_flops(T), BYTES_PER_UTT * T / 300.0
+            path_flops, path_bytes = total_flops(T), BYTES_PER_UTT * T / 300.0 * act_bytes_scale
         else:                                       # per-utterance lengths: sum the per-layer FLOPs
             per = [layer_flops(t) for t in lengths]
             lf = [sum(p[i] for p in per) for i in range(5)]
             n_done = world * K * B
             frames_done = world * K * sum(lengths)
             path_flops = (sum(lf) + B * 2 * 3000 * 512) / B
-            path_bytes = BYTES_PER_UTT * (sum(lengths) / B) / 300.0
+            path_bytes = BYTES_PER_UTT * (sum(lengths) / B) / 300.0 * act_bytes_scale
         tdnn_names = names[:5]
         tdnn_ms = sum(avg_ms[n] for n in tdnn_names)
         # dominant kernel: the plain tdnn_f32_kernel instance (layers 2-4 launch the same code object)

@@ -190,6 +190,19 @@ def main():
         torch.cuda.synchronize(dev)
         dt_pcie_ovl = time.perf_counter() - t2
 
+    # ---- the same steps as ONE hipGraph replay each (model.graphed): what the launch gaps cost
+    dt_graph = None
+    if lengths is None and n_local is None and waves is None:
+        gp = model.graphed(x)
+        for _ in range(3):
+            gp(x)
+        torch.cuda.synchronize(dev)
+        t3 = time.perf_counter()
+        for _ in range(K):
+            gp(x)
+        torch.cuda.synchronize(dev)
+        dt_graph = time.perf_counter() - t3
+
     # ---- per-kernel durations: hipEvents recorded by the library on the launch stream -----
     model.set_profiling(True, dev)
     names = ("tdnn1", "tdnn2", "tdnn3", "tdnn4", "tdnn5_pool", "pool_finalize", "segment6")
@@ -254,6 +267,7 @@ def main():
                                    + "extract_x_vec layer 6, random-init weights seed 42",
                        "batch_per_gpu": B, "frames": T, "valid_frames_per_s": round(frames_done / dt, 1),
                        "pcie_inclusive_embeddings_per_s_per_gpu": round(K_pcie * B / dt_pcie, 1),
+                       "graph_replay_embeddings_per_s_per_gpu": round(K * B / dt_graph, 1) if dt_graph else None,
                        "pcie_inclusive_overlapped_embeddings_per_s_per_gpu":
                            round(K_pcie * B / dt_pcie_ovl, 1) if dt_pcie_ovl else None,
                        "sharding": f"utterance-sharded x{world}"

@@ -319,6 +319,15 @@ class XVectorModel(nn.Module):
         mode = _hip.MODE_XVEC7 if self.x_vec_extract_layer == 7 else _hip.MODE_XVEC6
         return self._run(x, mode, lengths)
 
+    def graphed(self, example: torch.Tensor, logits: bool = False) -> "GraphedPath":
+        """The whole path for one fixed shape [B, T, C] as ONE hipGraph (fixed-length batches only).
+
+        Small or bf16 batches are launch-bound (7-8 launches of 10-100 us); the library neither
+        synchronises nor allocates, so the launch sequence can be captured once and replayed:
+        `g = model.graphed(x0); y = g(x)` copies x into the graph's input buffer and replays.
+        The result tensor is owned by the graph and overwritten by the next call."""
+        return GraphedPath(self, example, logits)
+
     def extract_packed(self, x_packed: torch.Tensor, offsets: Sequence[int], logits: bool = False):
         """Ragged batch without padding: x_packed[sum(len), C], utterance i in rows
         [offsets[i], offsets[i+1])."""
@@ -394,3 +403,26 @@ class XVectorModel(nn.Module):
         [(x_vecs, labels, ids)]."""
         samples, labels, ids = batch
         return [(self.extract_x_vec(samples.float()), labels, ids)]
+
+
+class GraphedPath:
+    """Captured launch sequence of XVectorModel.extract_x_vec / forward for one input shape."""
+
+    def __init__(self, model: XVectorModel, example: torch.Tensor, logits: bool = False):
+        _require_gpu(example, "graphed")
+        self._x = example.detach().float().contiguous().clone()
+        fn = model.forward if logits else model.extract_x_vec
+        fn(self._x)                                    # weights packed, workspace sized, outside the capture
+        torch.cuda.synchronize(self._x.device)
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            self._y = fn(self._x)
+        self._model = model                            # keeps the engine (workspace, weights) alive
+
+    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        if x.shape != self._x.shape:
+            raise ValueError(f"graph captured for {tuple(self._x.shape)}, got {tuple(x.shape)}")
+        self._x.copy_(x, non_blocking=True)
+        self._graph.replay()
+        return self._y
+

@@ -199,6 +199,12 @@ def test_path_is_graph_capturable(gpu_model, synth):
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(static_out, gpu_model.extract_x_vec(x2))
+    # the packaged form
+    gp = gpu_model.graphed(x)
+    assert torch.equal(gp(x2), gpu_model.extract_x_vec(x2))
+    assert torch.equal(gp(x), eager)
+    with pytest.raises(ValueError):
+        gp(x[:2])
 
 
 def test_odd_input_width_and_short_utterances(synth):

@@ -302,6 +302,46 @@ def test_extreme_shapes(sd42, synth, precision, tol):
         m.extract_x_vec(torch.zeros(65536, 16, 24, device=DEV))
 
 
+@pytest.mark.parametrize("case,precision", [(c, "fp32") for c in range(12)] + [(c, "bf16") for c in (0, 3, 5, 8, 11)])
+def test_random_model_shapes_vs_oracle(synth, case, precision):
+    """Seeded random architectures and batches (widths that are not multiples of the tile sizes, odd
+    MFCC counts, with and without BatchNorm, fixed and ragged lengths, all three outputs) against the
+    fp64 oracle: the padding and guard paths of every kernel, not only the 24/512/512/1211 model."""
+    import xvector_amd as xa
+    rng = np.random.default_rng(1000 + case)
+    cin = int(rng.integers(5, 41))
+    hid = int(rng.choice([24, 32, 72, 96, 128, 136, 200, 256]))
+    xv = int(rng.integers(8, 70))
+    ncls = int(rng.integers(3, 60))
+    bn = bool(rng.integers(0, 2))
+    B = int(rng.integers(1, 10))
+    T = int(rng.integers(16, 140))
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in synth.make_state_dict(
+        seed=2000 + case, input_size=cin, hidden_size=hid, num_classes=ncls, x_vector_size=xv, batch_norm=bn).items()}
+    m = xa.XVectorModel(input_size=cin, hidden_size=hid, num_classes=ncls, x_vector_size=xv, batch_norm=bn,
+                        precision=precision)
+    m.load_state_dict(sd)
+    m = m.to(DEV)
+    p64 = oracle.cast_params(float_params(sd), torch.float64)
+    x = torch.from_numpy(rng.standard_normal((B, T, cin), dtype=np.float32))
+    what = f"case {case} {precision}: cin={cin} hid={hid} xv={xv} cls={ncls} bn={bn} B={B} T={T}"
+    tol, et = (1e-4, None) if precision == "fp32" else (1e-2, 4e-2)
+
+    def check(got, ref, tag):
+        assert_parity(got, ref, tol, what + tag, elem_tol=et)
+
+    check(m.extract_x_vec(x.to(DEV)), oracle.extract_x_vec(x.double(), p64, batch_norm=bn), " xvec6")
+    check(m(x.to(DEV)), oracle.forward(x.double(), p64, batch_norm=bn), " logits")
+    m.x_vec_extract_layer = 7
+    check(m.extract_x_vec(x.to(DEV)), oracle.extract_x_vec(x.double(), p64, layer=7, batch_norm=bn), " xvec7")
+    m.x_vec_extract_layer = 6
+    if T >= 17 and B > 1:
+        lens = rng.integers(16, T + 1, B)
+        got = m.extract_x_vec(x.to(DEV), lengths=lens.tolist())
+        ref = torch.cat([oracle.extract_x_vec(x[i:i + 1, :int(lens[i])].double(), p64, batch_norm=bn) for i in range(B)])
+        check(got, ref, " ragged")
+
+
 def test_errors_are_loud(gpu_model):
     with pytest.raises(RuntimeError):
         gpu_model.extract_x_vec(torch.zeros(1, 300, 24))           # CPU tensor: no fallback

@@ -33,7 +33,14 @@ enum { XVEC_OK = 0, XVEC_ERR_ARG = 1, XVEC_ERR_HIP = 2, XVEC_ERR_STATE = 3, XVEC
 
 /* arithmetic of the frame-level stack (accumulation, pooling and the segment-level
  * affines are fp32 in both) */
-enum { XVEC_F32 = 0, XVEC_BF16 = 1 };
+enum {
+    XVEC_F32 = 0,   /* exact fp32 on v_mfma_f32_32x32x2_f32 (the reference's arithmetic) */
+    XVEC_BF16 = 1,  /* bf16 activations and weights (parity bar 1e-2) */
+    /* fp32 values carried as two bf16 planes (hi + lo), three bf16 products per k-step
+     * (x_hi*W_hi + x_lo*W_hi + x_hi*W_lo; every product is exact in the fp32 accumulator, what is
+     * dropped is 2^-16 relative): fp32-level results (parity bar 1e-4, as XVEC_F32) at bf16 matrix rates */
+    XVEC_BF16X3 = 2
+};
 
 /* what xvec_forward returns */
 enum {

@@ -67,19 +67,26 @@ hipError_t launch_pack_tdnn(const float* W, const float* bias, const float* g, c
 // (32-channel column tile, 16-wide k-step) are one contiguous KiB, so a wave fetches them with a
 // single coalesced 16-byte-per-lane load and the weights never pass through LDS.
 __global__ void pack_tdnn_weight_frag_kernel(const float* __restrict__ W, TdnnGeom g, __bf16* __restrict__ Wf) {
-    const int64_t total = (int64_t)g.n_pad * g.k_pad;
-    const int ksteps = g.k_pad / 16;
+    // g.terms == 3 (bf16x3): the stream holds every 64-wide chunk three times -- W_hi (for x_hi), W_hi
+    // again (for x_lo), W_lo (for x_hi) -- in the order the kernel walks them; W = W_hi + W_lo + O(2^-17)
+    const int terms = g.terms > 1 ? g.terms : 1;
+    const int64_t total = (int64_t)g.n_pad * g.k_pad * terms;
+    const int ksteps = g.k_pad * terms / 16;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
          i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t blk = i >> 9;
         const int within = (int)(i & 511), lane = within >> 3, j = within & 7;
         const int ct = (int)(blk / ksteps), ks = (int)(blk % ksteps);
-        const int n = ct * 32 + (lane & 31), kd = tap_major_k(g, ks * 16 + 8 * (lane >> 5) + j);
+        const int ks_stream = ks * 16 + 8 * (lane >> 5) + j;                 // position in the chunk stream
+        const int chunk_s = ks_stream / g.chunk_k, w = ks_stream % g.chunk_k;
+        const int term = chunk_s % terms, chunk = chunk_s / terms;
+        const int n = ct * 32 + (lane & 31), kd = tap_major_k(g, chunk * g.chunk_k + w);
         const int tap = kd / g.tap_stride_src, c = kd % g.tap_stride_src;
         float v = 0.f;
         if (n < g.cout && tap < g.src_taps && c < g.src_cin)
             v = W[(int64_t)n * (g.src_taps * g.src_cin) + tap * g.src_cin + c];
-        Wf[i] = (__bf16)v;
+        const __bf16 hi = (__bf16)v;
+        Wf[i] = (term == 2) ? (__bf16)(v - (float)hi) : hi;
     }
 }
 
@@ -104,6 +111,28 @@ __global__ void pack_rows_kernel(const float* __restrict__ x, const int64_t* __r
         const int c = (int)(i % c_pad);
         dst[i] = (TO)((c < C) ? src[t * C + c] : 0.f);
     }
+}
+
+// x[rows][C] fp32 -> two bf16 planes out[plane][rows_alloc][c_pad]: hi = bf16(x), lo = bf16(x - hi)
+__global__ void pack_rows_split_kernel(const float* __restrict__ x, int64_t rows, int C, int c_pad,
+                                       int64_t plane_elems, __bf16* __restrict__ out) {
+    const int64_t total = rows * c_pad;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / c_pad;
+        const int c = (int)(i % c_pad);
+        const float v = (c < C) ? x[r * C + c] : 0.f;
+        const __bf16 hi = (__bf16)v;
+        out[i] = hi;
+        out[plane_elems + i] = (__bf16)(v - (float)hi);
+    }
+}
+
+hipError_t launch_pack_rows_split(const float* x, int64_t rows, int C, int c_pad, int64_t plane_elems, void* out,
+                                  hipStream_t s) {
+    if (rows <= 0) return hipSuccess;
+    pack_rows_split_kernel<<<2048, 256, 0, s>>>(x, rows, C, c_pad, plane_elems, static_cast<__bf16*>(out));
+    return hipGetLastError();
 }
 
 hipError_t launch_pack_rows(const float* x, const int64_t* offsets, int B, int T, int C, int c_pad,

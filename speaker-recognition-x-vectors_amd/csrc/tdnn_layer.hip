@@ -70,6 +70,7 @@ struct Ctx {
     int64_t m0;          // first flat row of the tile the load stream is in
     int64_t g_s, g_end;  // that tile's first row group; end of this block's row range
     PoolCur pool;        // compute side: pooling cursor (POOL variants)
+    int term, term_off;  // bf16x3: which of the three products this chunk is; byte offset of its X plane
     int tap, kc, itl;    // next chunk to fetch: (tap, kc) and its linear index within the tile
     int es;              // bytes per input element (4: fp32, 2: bf16)
 };
@@ -147,12 +148,24 @@ __device__ __forceinline__ void set_tile_rows(const TdnnArgs& a, Ctx& cx) {
 template <bool GUARD>
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t x_rsrc(const TdnnArgs& a, const Ctx& cx) {
     const int64_t off = cx.m0 * (int64_t)a.ldx * cx.es;
-    if (GUARD) return make_rsrc_bounded(a.X, off, a.x_rows * (int64_t)a.ldx * cx.es);
+    if (GUARD) return make_rsrc_bounded(a.X, off, a.x_bytes ? a.x_bytes : a.x_rows * (int64_t)a.ldx * cx.es);
     return make_rsrc(static_cast<const char*>(a.X) + off);
 }
 
-template <bool GUARD>
+template <bool GUARD, bool X3>
 __device__ __forceinline__ void advance(const TdnnArgs& a, Ctx& cx, int n_chunks) {
+    if (X3 && cx.itl + 1 < n_chunks && cx.term < 2) {
+        // bf16x3: same chunk again -- product 1 reads the lo plane of X, product 2 the hi plane (with
+        // the lo weights, which simply follow in the packed stream)
+        ++cx.itl;
+        ++cx.term;
+        cx.term_off = cx.term == 1 ? a.x_plane_bytes : 0;
+        return;
+    }
+    if (X3) {
+        cx.term = 0;
+        cx.term_off = 0;
+    }
     if (cx.itl + 1 < n_chunks) {
         // taps innermost: consecutive chunks re-read the same 128-byte slab of activation rows,
         // shifted by the dilation, while it is still in L2 (the packed weights follow this order)
@@ -198,7 +211,7 @@ __device__ __forceinline__ void advance(const TdnnArgs& a, Ctx& cx, int n_chunks
 #define XV_GLD_A(i_, n_)                                                                                  \
     if constexpr (G > i_) {                                                                               \
         const int row_shift = cx.tap * a.tap_rows;                                                        \
-        const int soff = ((row_shift + 32 * i_) * a.ldx + cx.kc * BKE) * ES;                              \
+        const int soff = ((row_shift + 32 * i_) * a.ldx + cx.kc * BKE) * ES + (X3 ? cx.term_off : 0);     \
         if (GUARD) {                                                                                      \
             /* K past the layer's width (the folded taps of the next frame): an offset the descriptor's   \
                range check rejects, so the piece reads as zeros; rows past the tensor: same check */      \
@@ -257,6 +270,8 @@ __device__ __forceinline__ void advance(const TdnnArgs& a, Ctx& cx, int n_chunks
 // One K-chunk held in LDS buffer P_; N_ = the other buffer = the staging set holding chunk it+1.
 // Branch-free: the last chunk of a tile also stores/loads/reads ahead (clamped to the last
 // chunk, results unused) -- n_chunks is even, so the two-chunk loop body needs no tail variants.
+// (parenthesised: the template argument list must not be split by the slot macros' commas)
+#define XV_ADVANCE (advance<GUARD, X3>)(a, cx, n_chunks);
 #define XV_CHUNK(P_, N_, IT_)                                                                             \
     {                                                                                                     \
         const float* S = smem + P_ * kStageFloats;                                                        \
@@ -265,7 +280,7 @@ __device__ __forceinline__ void advance(const TdnnArgs& a, Ctx& cx, int n_chunks
               XV_FRG_A(3, 1, 1, S), XV_FRG_B(1, 1, S),                                                    \
               XV_LST_A(0, N_), XV_LST_A(1, N_), XV_LST_A(2, N_), XV_LST_A(3, N_),                         \
               XV_LST_B(0, N_), XV_LST_B(1, N_), XV_LST_B(2, N_), XV_LST_B(3, N_),                         \
-              XV_GLB(3, N_, (IT_) + 1), XV_NOP, advance<GUARD>(a, cx, n_chunks);)                                \
+              XV_GLB(3, N_, (IT_) + 1), XV_NOP, XV_ADVANCE)                                \
         XV_KG(1, P_, 1, XV_FRG_A(0, 2, 0, S), XV_FRG_A(1, 2, 0, S), XV_FRG_A(2, 2, 0, S),                 \
               XV_FRG_A(3, 2, 0, S), XV_FRG_B(2, 0, S),                                                    \
               XV_GLD_A(0, N_), XV_GLD_A(1, N_), XV_GLD_A(2, N_), XV_GLD_A(3, N_),                         \
@@ -297,19 +312,19 @@ struct Lane {
 
 // Once per block: chunk 0 of the first tile -> LDS buffer 0, its first fragments -> set 0,
 // chunks 1 and 2 in flight in the two staging sets.
-template <bool GUARD, bool INBF>
+template <bool GUARD, bool INBF, bool X3>
 __device__ __forceinline__ void block_prologue(const TdnnArgs& a, float* smem, Ctx& cx, Regs& rg, const Lane& ln,
                                                int n_chunks) {
     constexpr int G = 4;   // fetch all four row groups: rows past a short first tile are allocated
     constexpr int ES = INBF ? 2 : 4, BKE = 128 / ES;
     const int h = ln.h, sw = ln.sw, a_rd = ln.a_rd, b_rd = ln.b_rd, st_off = ln.st_off, c = ln.c;
     XV_GLD_ALL(0)
-    advance<GUARD>(a, cx, n_chunks);
+    advance<GUARD, X3>(a, cx, n_chunks);
     XV_GLD_ALL(1)
     SB();
     XV_LST_ALL(0)
     SB();
-    advance<GUARD>(a, cx, n_chunks);
+    advance<GUARD, X3>(a, cx, n_chunks);
     XV_GLD_ALL(0)
     __syncthreads();
     XV_FRG_A(0, 0, 0, smem) XV_FRG_A(1, 0, 0, smem) XV_FRG_A(2, 0, 0, smem) XV_FRG_A(3, 0, 0, smem)
@@ -321,7 +336,7 @@ __device__ __forceinline__ void block_prologue(const TdnnArgs& a, float* smem, C
 
 // One tile of G row groups (32 frames each) x 128 channels, starting at row group g0.  On entry
 // the pipeline is primed for this tile (block_prologue or the previous tile's last chunks).
-template <int G, bool GUARD, bool POOL, bool STORE, bool INBF, bool OUTBF>
+template <int G, bool GUARD, bool POOL, bool STORE, bool INBF, bool OUTBF, bool X3>
 __device__ __forceinline__ void process_tile(const TdnnArgs& a, float* smem, Ctx& cx, Regs& rg, const Lane& ln,
                                              int64_t g0, int n0, int n_chunks) {
     constexpr int ES = INBF ? 2 : 4, BKE = 128 / ES;
@@ -359,8 +374,11 @@ __device__ __forceinline__ void process_tile(const TdnnArgs& a, float* smem, Ctx
     const int esz = OUTBF ? 2 : 4;
     __amdgpu_buffer_rsrc_t yrsrc;
     int y_voff = 0;
+    __amdgpu_buffer_rsrc_t yrsrc_lo;     // bf16x3: descriptor of the lo plane (same offsets as the hi plane)
     if (STORE) {
         yrsrc = make_rsrc(static_cast<char*>(a.Y) + (m0 * (int64_t)a.ldy + n0) * esz);
+        if constexpr (X3 && OUTBF)
+            yrsrc_lo = make_rsrc(static_cast<char*>(a.Y) + a.y_plane_bytes + (m0 * (int64_t)a.ldy + n0) * esz);
         y_voff = (4 * h * a.ldy + (col - n0)) * esz;
     }
 #define XV_EPI(i_)                                                                                        \
@@ -375,6 +393,11 @@ __device__ __forceinline__ void process_tile(const TdnnArgs& a, float* smem, Ctx
                     const __bf16 hv = (__bf16)acc##i_[e];                                                 \
                     __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, hv), yrsrc,  \
                                                           y_voff, soff, 0);                               \
+                    if constexpr (X3) { /* bf16x3: the remainder goes to the lo plane */                  \
+                        const __bf16 lv = (__bf16)(acc##i_[e] - (float)hv);                               \
+                        __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, lv),     \
+                                                              yrsrc_lo, y_voff, soff, 0);                 \
+                    }                                                                                     \
                 } else {                                                                                  \
                     const float fv = acc##i_[e]; /* scalar copy: bit_cast of a vector ELEMENT is miscompiled */ \
                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(fv), yrsrc, y_voff, soff, 0);   \
@@ -399,7 +422,7 @@ __device__ __forceinline__ void process_tile(const TdnnArgs& a, float* smem, Ctx
 #endif
 }
 
-template <bool GUARD, bool POOL, bool STORE, bool INBF, bool OUTBF>
+template <bool GUARD, bool POOL, bool STORE, bool INBF, bool OUTBF, bool X3>
 __global__ __launch_bounds__(256, 2) void tdnn_kernel(const TdnnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
 #ifdef XVEC_DIAG
@@ -432,7 +455,7 @@ __global__ __launch_bounds__(256, 2) void tdnn_kernel(const TdnnArgs a) {
         g_end = a.groups_total * (int64_t)(p + 1) / a.blocks_per_col;
     }
     const int n0 = j * kBN;
-    const int n_chunks = a.n_taps * a.cpt;
+    const int n_chunks = a.n_taps * a.cpt * (X3 ? 3 : 1);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -478,15 +501,17 @@ __global__ __launch_bounds__(256, 2) void tdnn_kernel(const TdnnArgs a) {
     cx.tap = 0;
     cx.kc = 0;
     cx.itl = 0;
+    cx.term = 0;
+    cx.term_off = 0;
 
     Regs rg;
-    block_prologue<GUARD, INBF>(a, smem, cx, rg, ln, n_chunks);
+    block_prologue<GUARD, INBF, X3>(a, smem, cx, rg, ln, n_chunks);
     int64_t g = g_begin;
-    for (; g + 4 <= g_end; g += 4) process_tile<4, GUARD, POOL, STORE, INBF, OUTBF>(a, smem, cx, rg, ln, g, n0, n_chunks);
+    for (; g + 4 <= g_end; g += 4) process_tile<4, GUARD, POOL, STORE, INBF, OUTBF, X3>(a, smem, cx, rg, ln, g, n0, n_chunks);
     const int rem = (int)(g_end - g);
-    if (rem == 3) process_tile<3, GUARD, POOL, STORE, INBF, OUTBF>(a, smem, cx, rg, ln, g, n0, n_chunks);
-    else if (rem == 2) process_tile<2, GUARD, POOL, STORE, INBF, OUTBF>(a, smem, cx, rg, ln, g, n0, n_chunks);
-    else if (rem == 1) process_tile<1, GUARD, POOL, STORE, INBF, OUTBF>(a, smem, cx, rg, ln, g, n0, n_chunks);
+    if (rem == 3) process_tile<3, GUARD, POOL, STORE, INBF, OUTBF, X3>(a, smem, cx, rg, ln, g, n0, n_chunks);
+    else if (rem == 2) process_tile<2, GUARD, POOL, STORE, INBF, OUTBF, X3>(a, smem, cx, rg, ln, g, n0, n_chunks);
+    else if (rem == 1) process_tile<1, GUARD, POOL, STORE, INBF, OUTBF, X3>(a, smem, cx, rg, ln, g, n0, n_chunks);
 #ifdef XVEC_DIAG
     if (threadIdx.x == 0 && blockIdx.x < 8192) {
         __builtin_amdgcn_s_waitcnt(0);
@@ -498,9 +523,9 @@ __global__ __launch_bounds__(256, 2) void tdnn_kernel(const TdnnArgs a) {
 #endif
 }
 
-template <bool GUARD, bool POOL, bool STORE, bool INBF, bool OUTBF>
+template <bool GUARD, bool POOL, bool STORE, bool INBF, bool OUTBF, bool X3 = false>
 static hipError_t launch_variant(const TdnnArgs& a, hipStream_t s) {
-    auto kern = tdnn_kernel<GUARD, POOL, STORE, INBF, OUTBF>;
+    auto kern = tdnn_kernel<GUARD, POOL, STORE, INBF, OUTBF, X3>;
     static bool attr_set = false;   // per-variant; benign if raced (idempotent)
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -522,15 +547,22 @@ extern "C" int xvec_diag_read(unsigned long long* host, int n_words) {
 hipError_t launch_tdnn(const TdnnArgs& a, TdnnVariant v, hipStream_t s) {
     if (a.groups_total <= 0 || a.blocks_per_col <= 0 || a.blocks_per_col > a.groups_total || (a.cpt & 1))
         return hipErrorInvalidValue;
+    const bool x3 = a.terms == 3;     // bf16x3: compile-time mode of the bf16 instantiations
     switch (v) {
         case TdnnVariant::kF32First: return launch_variant<true, false, true, false, false>(a, s);
         case TdnnVariant::kF32: return launch_variant<false, false, true, false, false>(a, s);
         case TdnnVariant::kF32Pool: return launch_variant<false, true, false, false, false>(a, s);
         case TdnnVariant::kF32PoolStore: return launch_variant<false, true, true, false, false>(a, s);
-        case TdnnVariant::kBf16First: return launch_variant<true, false, true, true, true>(a, s);
-        case TdnnVariant::kBf16: return launch_variant<false, false, true, true, true>(a, s);
-        case TdnnVariant::kBf16Pool: return launch_variant<false, true, false, true, false>(a, s);
-        case TdnnVariant::kBf16ToF32: return launch_variant<false, false, true, true, false>(a, s);
+        case TdnnVariant::kBf16First:
+            return x3 ? launch_variant<true, false, true, true, true, true>(a, s) : launch_variant<true, false, true, true, true>(a, s);
+        case TdnnVariant::kBf16:
+            return x3 ? launch_variant<false, false, true, true, true, true>(a, s) : launch_variant<false, false, true, true, true>(a, s);
+        case TdnnVariant::kBf16Pool:
+            return x3 ? launch_variant<false, true, false, true, false, true>(a, s) : launch_variant<false, true, false, true, false>(a, s);
+        case TdnnVariant::kBf16ToF32:
+            return x3 ? launch_variant<false, false, true, true, false, true>(a, s) : launch_variant<false, false, true, true, false>(a, s);
+        case TdnnVariant::kBf16FirstToF32:
+            return x3 ? launch_variant<true, false, true, true, false, true>(a, s) : launch_variant<true, false, true, true, false>(a, s);
     }
     return hipErrorInvalidValue;
 }

@@ -47,6 +47,7 @@ struct xvec_handle {
     TdnnGeom geo[XVEC_NUM_TDNN];
     TdnnGeom geo16[XVEC_NUM_TDNN];     // bf16 packing of layers 2-5: 64-element chunks (layer 1 stays fp32)
     void* Wp16[XVEC_NUM_TDNN];         // bf16, fragment-major
+    void* Wp48[XVEC_NUM_TDNN];         // bf16x3: the hi/hi/lo chunk stream (3x the size), fragment-major
     float* Wp[XVEC_NUM_TDNN];
     float* vec[XVEC_NUM_TDNN];         // bias | scale | shift, n_pad each
     bool tdnn_loaded[XVEC_NUM_TDNN];
@@ -85,7 +86,7 @@ Plan make_plan(const xvec_handle* h, int64_t total, int B) {
     const int nh = h->geo[0].n_pad, n5 = h->geo[4].n_pad;
     size_t o = 0;
     p.xpad = o;   o += align_up((size_t)p.rows_alloc * h->cin_pad * 4);
-    p.x16 = o;    o += align_up((size_t)p.rows_alloc * h->cin_pad * 2);
+    p.x16 = o;    o += align_up((size_t)p.rows_alloc * h->cin_pad * 2 * 2);   // bf16 rows; bf16x3: hi and lo planes
     p.actA = o;   o += align_up((size_t)p.rows_alloc * nh * 4);
     p.actB = o;   o += align_up((size_t)p.rows_alloc * nh * 4);
     p.act5 = o;   o += align_up((size_t)p.rows_alloc * n5 * 4);
@@ -150,10 +151,12 @@ struct StageTimer {
 
 // Launch one frame-level layer on flat rows.  The variant selects arithmetic and epilogue; bf16
 // variants use the bf16 packing (64-element chunks) of the layer's weights.
+// x3: bf16x3 arithmetic -- X (and Y, when it is bf16) are two bf16 planes `x_plane` / `y_plane` bytes apart
 int run_tdnn(xvec_handle* h, int layer, TdnnVariant v, const void* X, int ldx, int64_t x_rows, void* Y,
-             int64_t rows_out, const RowMap& out_map, float* part, hipStream_t s) {
+             int64_t rows_out, const RowMap& out_map, float* part, hipStream_t s, bool x3 = false,
+             int64_t x_plane = 0, int64_t y_plane = 0) {
     const bool in16 = v == TdnnVariant::kBf16 || v == TdnnVariant::kBf16Pool || v == TdnnVariant::kBf16ToF32 ||
-                      v == TdnnVariant::kBf16First;
+                      v == TdnnVariant::kBf16First || v == TdnnVariant::kBf16FirstToF32;
     const TdnnGeom& g = in16 ? h->geo16[layer] : h->geo[layer];
     TdnnArgs a;
     memset(&a, 0, sizeof(a));
@@ -188,6 +191,17 @@ int run_tdnn(xvec_handle* h, int layer, TdnnVariant v, const void* X, int ldx, i
     a.pool_part = part;
     a.out_map = out_map;
     a.span = h->geo[layer].ctx_span;
+    a.terms = 1;
+    if (x3) {
+        if (x_plane > 0x3fffffff || y_plane > 0x3fffffff)
+            return fail(XVEC_ERR_ARG, "batch too large for bf16x3 (plane offsets must fit 30 bits); split it");
+        a.terms = 3;
+        a.Wf = h->Wp48[layer];
+        a.k_pad = 3 * g.k_pad;
+        a.x_plane_bytes = (int)x_plane;
+        a.y_plane_bytes = (int)y_plane;
+        a.x_bytes = x_rows > 0 ? x_plane + x_rows * (int64_t)ldx * 2 : 0;
+    }
     StageTimer t(h, T_L1 + layer, s);
     HIP_TRY(launch_tdnn(a, v, s));
     return XVEC_OK;
@@ -214,9 +228,11 @@ int forward_rows(xvec_handle* h, const float* x_rows, int ldx, const int64_t* of
     float* s7 = reinterpret_cast<float*>(ws + p.seg7);
     const int nh = h->geo[0].n_pad;
     int rc;
-    const bool b16 = dtype == XVEC_BF16;
+    const bool x3 = dtype == XVEC_BF16X3;
+    const bool b16 = dtype == XVEC_BF16 || x3;
     // layer 1 reads the caller's rows (guarded against the end of the buffer and the K tail); in
-    // bf16 mode the MFCC rows are first rounded to bf16 into the workspace.
+    // bf16 mode the MFCC rows are first rounded to bf16 into the workspace (bf16x3: split into a hi
+    // and a lo plane; every activation buffer then holds two bf16 planes in the space of one fp32).
     // Layer 5 carries the statistics-pooling epilogue: its [frames,1500] output stays on chip.
     const TdnnVariant v1 = b16 ? TdnnVariant::kBf16First : TdnnVariant::kF32First;
     const TdnnVariant vm = b16 ? TdnnVariant::kBf16 : TdnnVariant::kF32;
@@ -231,11 +247,18 @@ int forward_rows(xvec_handle* h, const float* x_rows, int ldx, const int64_t* of
     void* bufs[2] = {actA, actB};
     const void* in = x_rows;
     int ld_in = ldx;
+    const int64_t act_plane = p.rows_alloc * (int64_t)nh * 2;        // bytes of one bf16 plane of an activation buffer
+    int64_t in_plane = 0;
     if (b16) {   // [total, ldx] fp32 -> bf16 (same row stride in elements)
         if (p.total > 0x7fffffff) return fail(XVEC_ERR_ARG, "too many frames for one bf16 batch");
         StageTimer t(h, T_PACK, s);
         void* x16 = ws + p.x16;
-        HIP_TRY(launch_pack_rows(x_rows, nullptr, 1, (int)p.total, ldx, ldx, x16, true, s));
+        if (x3) {
+            in_plane = p.rows_alloc * (int64_t)ldx * 2;
+            HIP_TRY(launch_pack_rows_split(x_rows, p.total, ldx, ldx, in_plane / 2, x16, s));
+        } else {
+            HIP_TRY(launch_pack_rows(x_rows, nullptr, 1, (int)p.total, ldx, ldx, x16, true, s));
+        }
         in = x16;
     }
     for (int l = 0; l < XVEC_NUM_TDNN; ++l) {
@@ -243,10 +266,12 @@ int forward_rows(xvec_handle* h, const float* x_rows, int ldx, const int64_t* of
         const int64_t rows_out = p.total - (int64_t)B * map.cum;
         const TdnnVariant v = l == 0 ? v1 : l == 4 ? v5 : vm;
         void* out_buf = l == 4 ? nullptr : bufs[l & 1];
-        if ((rc = run_tdnn(h, l, v, in, ld_in, l == 0 ? p.total : 0, out_buf, rows_out, map, l == 4 ? part : nullptr, s)))
+        if ((rc = run_tdnn(h, l, v, in, ld_in, l == 0 ? p.total : 0, out_buf, rows_out, map, l == 4 ? part : nullptr, s,
+                           x3, in_plane, l == 4 ? 0 : act_plane)))
             return rc;
         in = out_buf;
         ld_in = nh;
+        in_plane = act_plane;
     }
     {
         StageTimer t(h, T_POOL, s);
@@ -313,7 +338,7 @@ int common_checks(xvec_handle* h, const void* x, int B, int mode, int dtype, con
     if (B < 1 || B > 65535) return fail(XVEC_ERR_ARG, "B must be in [1, 65535] (got %d); split larger batches", B);
     if (mode != XVEC_MODE_LOGITS && mode != XVEC_MODE_XVEC6 && mode != XVEC_MODE_XVEC7)
         return fail(XVEC_ERR_ARG, "unknown mode %d", mode);
-    if (dtype != XVEC_F32 && dtype != XVEC_BF16) return fail(XVEC_ERR_ARG, "unknown dtype %d", dtype);
+    if (dtype != XVEC_F32 && dtype != XVEC_BF16 && dtype != XVEC_BF16X3) return fail(XVEC_ERR_ARG, "unknown dtype %d", dtype);
     if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(ws) & 255))
         return fail(XVEC_ERR_ARG, "x must be 16-byte and workspace 256-byte aligned");
     return check_loaded(h, mode);
@@ -352,6 +377,7 @@ int xvec_create(const xvec_cfg* cfg, xvec_handle** out) {
     for (int i = 0; i < XVEC_NUM_TDNN; ++i) {
         const TdnnGeom& g = h->geo[i];
         if (hipMalloc(&h->Wp16[i], (size_t)h->geo16[i].n_pad * h->geo16[i].k_pad * 2) != hipSuccess ||
+            hipMalloc(&h->Wp48[i], (size_t)h->geo16[i].n_pad * h->geo16[i].k_pad * 2 * 3) != hipSuccess ||
             hipMalloc(reinterpret_cast<void**>(&h->Wp[i]), (size_t)g.n_pad * g.k_pad * 4) != hipSuccess ||
             hipMalloc(reinterpret_cast<void**>(&h->vec[i]), (size_t)3 * g.n_pad * 4) != hipSuccess) {
             xvec_destroy(h);
@@ -385,6 +411,7 @@ void xvec_destroy(xvec_handle* h) {
     for (int i = 0; i < XVEC_NUM_TDNN; ++i) {
         if (h->Wp[i]) (void)hipFree(h->Wp[i]);
         if (h->Wp16[i]) (void)hipFree(h->Wp16[i]);
+        if (h->Wp48[i]) (void)hipFree(h->Wp48[i]);
         if (h->vec[i]) (void)hipFree(h->vec[i]);
     }
     for (int i = 0; i < 3; ++i) {
@@ -414,6 +441,11 @@ int xvec_load_tdnn(xvec_handle* h, int layer, const float* weight, const float* 
                              h->vec[layer], h->vec[layer] + g.n_pad, h->vec[layer] + 2 * g.n_pad,
                              static_cast<hipStream_t>(stream)));
     HIP_TRY(launch_pack_tdnn_bf16(weight, h->geo16[layer], h->Wp16[layer], static_cast<hipStream_t>(stream)));
+    {
+        TdnnGeom g3 = h->geo16[layer];
+        g3.terms = 3;
+        HIP_TRY(launch_pack_tdnn_bf16(weight, g3, h->Wp48[layer], static_cast<hipStream_t>(stream)));
+    }
     h->tdnn_loaded[layer] = true;
     return XVEC_OK;
 }
@@ -525,7 +557,7 @@ int xvec_tdnn_layer(xvec_handle* h, int layer, const float* x, int32_t B, int32_
                     void* workspace, size_t workspace_bytes, xvec_stream stream) {
     if (!h || layer < 0 || layer >= XVEC_NUM_TDNN) return fail(XVEC_ERR_ARG, "bad handle or layer %d", layer);
     if (!x || !y || !workspace) return fail(XVEC_ERR_ARG, "null tensor pointer");
-    if (dtype != XVEC_F32 && dtype != XVEC_BF16) return fail(XVEC_ERR_ARG, "unknown dtype %d", dtype);
+    if (dtype != XVEC_F32 && dtype != XVEC_BF16 && dtype != XVEC_BF16X3) return fail(XVEC_ERR_ARG, "unknown dtype %d", dtype);
     if (!h->tdnn_loaded[layer]) return fail(XVEC_ERR_STATE, "time_context_layers.%d weights not loaded", layer);
     const TdnnGeom& g = h->geo[layer];
     if (B < 1 || T <= g.ctx_span) return fail(XVEC_ERR_ARG, "need B>=1 and T>%d (got B=%d T=%d)", g.ctx_span, B, T);
@@ -536,22 +568,31 @@ int xvec_tdnn_layer(xvec_handle* h, int layer, const float* x, int32_t B, int32_
     char* ws = static_cast<char*>(workspace);
     // bf16 mode: activations between layers are bf16 (layer 1 still reads fp32 MFCCs); the result is
     // widened back to fp32 for the caller
+    const bool x3 = dtype == XVEC_BF16X3;
     const bool b16 = dtype == XVEC_BF16;
-    const bool in16 = b16;
+    const bool in16 = b16 || x3;
     // stage the compact input into the layer's native row layout (stride = producer's n_pad)
     const int ldx = (layer == 0) ? h->cin_pad : h->geo[layer - 1].n_pad;
-    void* xin = ws + (layer == 0 ? p.xpad : p.actA);
-    HIP_TRY(launch_pack_rows(x, nullptr, B, T, g.src_cin, ldx, xin, in16, s));
-    void* yflat = ws + (layer == 4 ? p.act5 : p.actB);
-    const TdnnVariant v = layer == 0 ? (b16 ? TdnnVariant::kBf16First : TdnnVariant::kF32First)
-                                     : (b16 ? TdnnVariant::kBf16 : TdnnVariant::kF32);
+    void* xin = ws + (layer == 0 ? (in16 ? p.x16 : p.xpad) : p.actA);
+    int64_t x_plane = 0;
+    if (x3) {   // fp32 rows first (padding to ldx), then the hi/lo split; bf16x3 returns fp32 directly
+        void* x32 = ws + p.actB;
+        HIP_TRY(launch_pack_rows(x, nullptr, B, T, g.src_cin, ldx, x32, false, s));
+        x_plane = p.rows_alloc * (int64_t)ldx * 2;
+        HIP_TRY(launch_pack_rows_split(static_cast<const float*>(x32), p.total, ldx, ldx, x_plane / 2, xin, s));
+    } else {
+        HIP_TRY(launch_pack_rows(x, nullptr, B, T, g.src_cin, ldx, xin, in16, s));
+    }
+    void* yflat = ws + (layer == 4 || x3 ? p.act5 : p.actB);
+    const TdnnVariant v = layer == 0 ? (b16 ? TdnnVariant::kBf16First : x3 ? TdnnVariant::kBf16FirstToF32 : TdnnVariant::kF32First)
+                                     : (b16 ? TdnnVariant::kBf16 : x3 ? TdnnVariant::kBf16ToF32 : TdnnVariant::kF32);
     RowMap map;
     map.offsets = nullptr;
     map.n_utts = B;
     map.fixed_T = T;
     map.cum = g.ctx_span;
     const int To = T - g.ctx_span;
-    int rc = run_tdnn(h, layer, v, xin, ldx, p.total, yflat, (int64_t)B * To, map, nullptr, s);
+    int rc = run_tdnn(h, layer, v, xin, ldx, p.total, yflat, (int64_t)B * To, map, nullptr, s, x3, x_plane, 0);
     if (rc) return rc;
     HIP_TRY(launch_unpack_rows(yflat, b16, g.n_pad, B, To, To, g.cout, y, s));
     return XVEC_OK;

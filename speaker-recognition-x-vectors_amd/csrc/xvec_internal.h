@@ -59,6 +59,7 @@ struct TdnnGeom {
     int src_taps;       // taps in the PyTorch weight
     int src_cin;        // channels per tap in the PyTorch weight
     int chunk_k;        // K elements per 128-byte chunk (32 fp32, 64 bf16): unit of the packed K order
+    int terms;          // bf16x3 weight stream: 3 (chunk walked as hi, hi, lo), else 1
 };
 
 struct TdnnArgs {
@@ -81,6 +82,13 @@ struct TdnnArgs {
     int span;                 // frames this layer consumes (c[-1]-c[0]): input row = p + u(p)*span
     // fused statistics-pooling epilogue (layer 5)
     float* pool_part;         // [slots][2][n_pad] (mean, M2) per (32-row group, utterance)
+    // bf16x3 (fp32 values carried as two bf16 planes hi + lo, three bf16 products per k-step:
+    // x_hi*W_hi + x_lo*W_hi + x_hi*W_lo).  terms == 3: every K chunk is walked three times, the second
+    // time from the lo plane of X (x_plane_bytes further on); Wf holds the matching weight stream.
+    int terms;                // 1 (plain) or 3
+    int x_plane_bytes;        // byte distance from the hi plane of X to its lo plane
+    int y_plane_bytes;        // > 0: bf16 output as two planes, lo plane this many bytes after Y
+    int64_t x_bytes;          // guarded variant: readable bytes from X (0: x_rows * ldx * element size)
 };
 
 // kernel instantiations: input/weight arithmetic x epilogue
@@ -92,7 +100,8 @@ enum class TdnnVariant {
     kBf16First,       // layer 1 of the bf16 path: guarded reads of the bf16-converted MFCC rows
     kBf16,            // bf16 -> bf16
     kBf16Pool,        // bf16 -> pooling partials only
-    kBf16ToF32        // bf16 -> fp32 (per-layer test entry of layer 5)
+    kBf16ToF32,       // bf16 -> fp32 (per-layer test entry: layer 5, and every layer in bf16x3)
+    kBf16FirstToF32   // layer 1, guarded, bf16 -> fp32 (per-layer test entry in bf16x3)
 };
 hipError_t launch_tdnn(const TdnnArgs& a, TdnnVariant v, hipStream_t s);
 
@@ -126,6 +135,9 @@ hipError_t launch_pack_tdnn_bf16(const float* W, const TdnnGeom& geo, void* Wf16
 // x[B,T,C] (+lengths) -> packed rows [sum len, c_pad] (fp32 or bf16); offsets on device
 hipError_t launch_pack_rows(const float* x, const int64_t* offsets, int B, int T, int C, int c_pad,
                             void* out, bool out_bf16, hipStream_t s);
+// x[rows][C] fp32 -> bf16 planes hi | lo, each [.][c_pad], lo plane plane_elems elements after hi (bf16x3)
+hipError_t launch_pack_rows_split(const float* x, int64_t rows, int C, int c_pad, int64_t plane_elems, void* out,
+                                  hipStream_t s);
 // flat [rows, ld] (fp32 or bf16) -> compact fp32 y[B, T_out, C]
 hipError_t launch_unpack_rows(const void* flat, bool in_bf16, int ld, int B, int T_in, int T_out, int C,
                               float* y, hipStream_t s);

@@ -19,7 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("XVEC_LIB") or os.path.join(_HERE, "libxvec_hip.so")
 
 OK, ERR_ARG, ERR_HIP, ERR_STATE, ERR_WORKSPACE = 0, 1, 2, 3, 4
-F32, BF16 = 0, 1
+F32, BF16, BF16X3 = 0, 1, 2
 MODE_LOGITS, MODE_XVEC6, MODE_XVEC7 = 0, 6, 7
 SEG6, SEG7, OUTPUT = 6, 7, 8
 TIMING_NAMES = ("tdnn1", "tdnn2", "tdnn3", "tdnn4", "tdnn5_pool", "pool_finalize",

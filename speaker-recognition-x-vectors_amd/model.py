@@ -24,7 +24,7 @@ from . import hip as _hip
 TOTAL_CONTEXT = 14
 POOL_CHANNELS = 1500
 _CONTEXTS = [[-2, -1, 0, 1, 2], [-2, 0, 2], [-3, 0, 3], [0], [0]]
-_DTYPES = {"fp32": _hip.F32, "f32": _hip.F32, "bf16": _hip.BF16}
+_DTYPES = {"fp32": _hip.F32, "f32": _hip.F32, "bf16": _hip.BF16, "bf16x3": _hip.BF16X3}
 
 
 def get_time_context(x: torch.Tensor, c: Sequence[int] = (0,)) -> List[torch.Tensor]:
@@ -114,7 +114,9 @@ class XVectorModel(nn.Module):
     `augmentations_per_sample` and `data_folder_path` belong to its training harness and
     are accepted and stored only.  Extensions: every entry point takes an optional
     `lengths` (valid frames per utterance of a zero-padded batch, BASELINE config 3) and
-    `precision` selects the frame-level arithmetic ("fp32" default)."""
+    `precision` selects the frame-level arithmetic: "fp32" (default; exact fp32 MFMA, the reference's
+    arithmetic), "bf16" (parity bar 1e-2) or "bf16x3" (fp32 values carried as two bf16 planes, three
+    bf16 products per k-step: fp32-level results, parity bar 1e-4, at bf16 matrix rates)."""
 
     def __init__(self, input_size=24, hidden_size=512, num_classes=1211, x_vector_size=512,
                  x_vec_extract_layer=6, batch_size=512, learning_rate=0.001, batch_norm=True,

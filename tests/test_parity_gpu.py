@@ -264,7 +264,7 @@ def test_full_size_ragged(gpu_model, sd42, synth):
     assert_parity(out[i:i + 1], ref, 1e-4, "shortest vs oracle")
 
 
-@pytest.mark.parametrize("precision,tol", [("fp32", 1e-4), ("bf16", 1e-2)])
+@pytest.mark.parametrize("precision,tol", [("fp32", 1e-4), ("bf16", 1e-2), ("bf16x3", 1e-4)])
 def test_extreme_shapes(sd42, synth, precision, tol):
     """Shapes far from the bench batch: one very long utterance (its pooling partials span ~940
     row groups and every persistent block), thousands of minimal utterances (several utterances
@@ -278,7 +278,7 @@ def test_extreme_shapes(sd42, synth, precision, tol):
     x = synth.make_mfcc(1, 30000, seed=5)
     with torch.no_grad():
         ref = oracle.extract_x_vec(torch.from_numpy(x), p32)
-    assert_parity(m.extract_x_vec(_gpu(x)), ref, tol, "T=30000", elem_tol=None if precision == "fp32" else 2e-2)
+    assert_parity(m.extract_x_vec(_gpu(x)), ref, tol, "T=30000", elem_tol=2e-2 if precision == "bf16" else None)
     # (2) 3 000 utterances of 16..40 frames, ragged: 2..26 pooled frames each
     rng = np.random.default_rng(9)
     lens = rng.integers(16, 41, 3000)
@@ -288,21 +288,25 @@ def test_extreme_shapes(sd42, synth, precision, tol):
     idx = [0, 1, 2, 1499, 2998, 2999, int(lens.argmin()), int(lens.argmax())]
     with torch.no_grad():
         ref = torch.cat([oracle.extract_x_vec(torch.from_numpy(xs[i:i + 1, :int(lens[i])]), p32) for i in idx])
-    assert_parity(out[idx], ref, tol, "short ragged", elem_tol=None if precision == "fp32" else 3e-2)
+    assert_parity(out[idx], ref, tol, "short ragged", elem_tol=3e-2 if precision == "bf16" else None)
     # (3) the largest batch one call accepts (65 535 utterances), T=16: every row equals the
     # same utterance run alone
-    big = torch.from_numpy(synth.make_mfcc(5, 16, seed=7)).to(DEV).repeat(13107, 1, 1)
-    assert big.shape[0] == 65535
+    # (bf16x3 addresses its second plane with a 30-bit offset: half as many rows per call)
+    reps = 13107 if precision != "bf16x3" else 6000
+    big = torch.from_numpy(synth.make_mfcc(5, 16, seed=7)).to(DEV).repeat(reps, 1, 1)
+    n_big = 5 * reps
+    assert n_big == 65535 or precision == "bf16x3"
     outb = m.extract_x_vec(big)
     alone = m.extract_x_vec(big[:5])
     assert_parity(outb[:5], alone, 1e-5, "max batch head")
     assert_parity(outb[-5:], alone, 1e-5, "max batch tail")
-    assert torch.equal(outb[5:10], outb[65530:65535])
+    assert torch.equal(outb[5:10], outb[n_big - 5:n_big])
     with pytest.raises((ValueError, RuntimeError), match="65535"):
         m.extract_x_vec(torch.zeros(65536, 16, 24, device=DEV))
 
 
-@pytest.mark.parametrize("case,precision", [(c, "fp32") for c in range(12)] + [(c, "bf16") for c in (0, 3, 5, 8, 11)])
+@pytest.mark.parametrize("case,precision", [(c, "fp32") for c in range(12)] + [(c, "bf16") for c in (0, 3, 5, 8, 11)]
+                         + [(c, "bf16x3") for c in range(12)])
 def test_random_model_shapes_vs_oracle(synth, case, precision):
     """Seeded random architectures and batches (widths that are not multiples of the tile sizes, odd
     MFCC counts, with and without BatchNorm, fixed and ragged lengths, all three outputs) against the
@@ -325,7 +329,7 @@ def test_random_model_shapes_vs_oracle(synth, case, precision):
     p64 = oracle.cast_params(float_params(sd), torch.float64)
     x = torch.from_numpy(rng.standard_normal((B, T, cin), dtype=np.float32))
     what = f"case {case} {precision}: cin={cin} hid={hid} xv={xv} cls={ncls} bn={bn} B={B} T={T}"
-    tol, et = (1e-4, None) if precision == "fp32" else (1e-2, 4e-2)
+    tol, et = (1e-2, 4e-2) if precision == "bf16" else (1e-4, None)     # bf16x3 answers to the fp32 bar
 
     def check(got, ref, tag):
         assert_parity(got, ref, tol, what + tag, elem_tol=et)
@@ -403,3 +407,47 @@ def test_bf16_ragged_and_tiny(sd42, synth):
     mt.load_state_dict(sd)
     mt = mt.to(DEV)
     assert_parity(mt.extract_x_vec(_gpu(gt["bn/x"])), gt["bn/xvec6"], 1e-2, "bf16 tiny")
+
+
+# ------------------------------------------------------------------------------- bf16x3 path
+def _x3_model(sd42):
+    import xvector_amd as xa
+    m = xa.XVectorModel(precision="bf16x3")
+    m.load_state_dict(sd42)
+    return m.to(DEV)
+
+
+@pytest.mark.parametrize("B,T", [(1, 299), (8, 299), (1, 300), (8, 300)])
+def test_bf16x3_full_path_vs_golden(sd42, synth, B, T):
+    """Two bf16 planes, three bf16 products per k-step: held to the fp32 bar (1e-4) against the
+    REFERENCE's own outputs (fixtures g4), all three outputs."""
+    g = load_golden("g4_full.npz")
+    m = _x3_model(sd42)
+    key = f"B{B}_T{T}"
+    x = _gpu(synth.make_mfcc(B, T, seed=int(g[key + "_seed_x"])))
+    assert_parity(m.extract_x_vec(x), g[key + "_xvec6"], 1e-4, "x3 xvec6")
+    assert_parity(m(x), g[key + "_logits"], 1e-4, "x3 logits")
+    m.x_vec_extract_layer = 7
+    assert_parity(m.extract_x_vec(x), g[key + "_xvec7"], 1e-4, "x3 xvec7")
+
+
+def test_bf16x3_layers_and_full_size(gpu_model, sd42, synth):
+    """Every layer alone against the fp32 kernels (5e-5), the bench batch against them end to end,
+    ragged lengths, and the batch-size limit of the mode (plane offsets are 30-bit)."""
+    m = _x3_model(sd42)
+    x = _gpu(synth.make_mfcc(3, 120, seed=21))
+    h32, h3 = x, x
+    for l32, l3 in zip(gpu_model.time_context_layers, m.time_context_layers):
+        h32, h3 = l32(h32), l3(h32)            # same (fp32) input to both
+        assert_parity(h3, h32, 5e-5, "x3 layer", elem_tol=2e-4)
+    xb = _gpu(synth.make_mfcc(256, 300, seed=0))
+    out = m.extract_x_vec(xb)
+    assert_parity(out, gpu_model.extract_x_vec(xb), 2e-5, "x3 vs fp32, B=256")
+    assert torch.equal(out, m.extract_x_vec(xb))                      # deterministic
+    lens = synth.make_lengths(64)
+    xr = _gpu(synth.make_mfcc(64, int(lens.max()), seed=2))
+    assert_parity(m.extract_x_vec(xr, lengths=lens.tolist()), gpu_model.extract_x_vec(xr, lengths=lens.tolist()), 2e-5,
+                  "x3 ragged")
+    with pytest.raises(RuntimeError, match="bf16x3"):
+        m.extract_x_vec(torch.zeros(65535, 16, 24, device=DEV))
+

@@ -97,7 +97,8 @@ size_t xvec_workspace_bytes(const xvec_handle* h, int64_t total_frames, int32_t 
  *                 HOST array of B valid-frame counts, 15 <= lengths[i] <= T: utterance i
  *                 is x[i, :lengths[i]] and the result equals the reference run on that
  *                 un-padded slice alone (BASELINE config 3).
- *   mode:         XVEC_MODE_*;  dtype: XVEC_F32 / XVEC_BF16
+ *   mode:         XVEC_MODE_*;  dtype: XVEC_F32 / XVEC_BF16 / XVEC_BF16X3 (the last one: at most
+ *                 ~1M frames per call at 512 channels -- its second plane is addressed with 30 bits)
  *   out:          [B, num_classes] (logits) or [B, x_vector_size]
  * Errors: T (or a length) < 15 -> XVEC_ERR_ARG (the reference silently yields empty
  * tensors / NaN there); weights not loaded -> XVEC_ERR_STATE. */

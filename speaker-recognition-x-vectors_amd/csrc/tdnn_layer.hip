@@ -24,6 +24,10 @@
 //     pack.hip stores the weights' K axis in that order): the dilated taps re-read a 128-byte slab
 //     of activation rows while it is still in L2.  bf16: the weights are packed fragment-major and
 //     go from global memory straight into the MFMA B operand, only activations pass through LDS.
+//   * bf16x3 (template flag X3 of the bf16 instantiations): X and Y are two bf16 planes (hi, lo) of
+//     fp32 values; every chunk is walked three times -- hi plane, lo plane, hi plane -- against a weight
+//     stream packed as W_hi, W_hi, W_lo, which yields x_hi*W_hi + x_lo*W_hi + x_hi*W_lo with the same
+//     pipeline (fp32-level results: 1.5e-6 from the fp64 oracle).
 //   * each ds_read_b128 feeds four MFMAs: lane half h owns k = 8q+4h..8q+4h+3 of every
 //     8-wide k group, for A and B alike, so the products pair up (the k order inside a chunk
 //     is permuted, which fp32 addition tolerates to rounding).

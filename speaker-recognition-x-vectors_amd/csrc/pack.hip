@@ -67,8 +67,8 @@ hipError_t launch_pack_tdnn(const float* W, const float* bias, const float* g, c
 // (32-channel column tile, 16-wide k-step) are one contiguous KiB, so a wave fetches them with a
 // single coalesced 16-byte-per-lane load and the weights never pass through LDS.
 __global__ void pack_tdnn_weight_frag_kernel(const float* __restrict__ W, TdnnGeom g, __bf16* __restrict__ Wf) {
-    // g.terms == 3 (bf16x3): the stream holds every 64-wide chunk three times -- W_hi (for x_hi), W_hi
-    // again (for x_lo), W_lo (for x_hi) -- in the order the kernel walks them; W = W_hi + W_lo + O(2^-17)
+    // g.terms == 2 (bf16x3): the stream holds every 64-wide chunk twice -- its four W_hi k-step blocks,
+    // then its four W_lo blocks, W = W_hi + W_lo + O(2^-17) -- as the kernel's XV_GLB3 reads them
     const int terms = g.terms > 1 ? g.terms : 1;
     const int64_t total = (int64_t)g.n_pad * g.k_pad * terms;
     const int ksteps = g.k_pad * terms / 16;
@@ -86,7 +86,7 @@ __global__ void pack_tdnn_weight_frag_kernel(const float* __restrict__ W, TdnnGe
         if (n < g.cout && tap < g.src_taps && c < g.src_cin)
             v = W[(int64_t)n * (g.src_taps * g.src_cin) + tap * g.src_cin + c];
         const __bf16 hi = (__bf16)v;
-        Wf[i] = (term == 2) ? (__bf16)(v - (float)hi) : hi;
+        Wf[i] = (terms > 1 && term == terms - 1) ? (__bf16)(v - (float)hi) : hi;
     }
 }
 

@@ -25,9 +25,9 @@
 //     of activation rows while it is still in L2.  bf16: the weights are packed fragment-major and
 //     go from global memory straight into the MFMA B operand, only activations pass through LDS.
 //   * bf16x3 (template flag X3 of the bf16 instantiations): X and Y are two bf16 planes (hi, lo) of
-//     fp32 values; every chunk is walked three times -- hi plane, lo plane, hi plane -- against a weight
-//     stream packed as W_hi, W_hi, W_lo, which yields x_hi*W_hi + x_lo*W_hi + x_hi*W_lo with the same
-//     pipeline (fp32-level results: 1.5e-6 from the fp64 oracle).
+//     fp32 values; an LDS buffer holds the hi and the lo tile of a chunk, the weight stream its W_hi and
+//     W_lo fragments, and every k-step issues x_hi*W_hi + x_hi*W_lo + x_lo*W_hi (XV_CHUNK3; fp32-level
+//     results: 1.5e-6 from the fp64 oracle).
 //   * each ds_read_b128 feeds four MFMAs: lane half h owns k = 8q+4h..8q+4h+3 of every
 //     8-wide k group, for A and B alike, so the products pair up (the k order inside a chunk
 //     is permuted, which fp32 addition tolerates to rounding).
@@ -74,7 +74,6 @@ struct Ctx {
     int64_t m0;          // first flat row of the tile the load stream is in
     int64_t g_s, g_end;  // that tile's first row group; end of this block's row range
     PoolCur pool;        // compute side: pooling cursor (POOL variants)
-    int term, term_off;  // bf16x3: which of the three products this chunk is; byte offset of its X plane
     int tap, kc, itl;    // next chunk to fetch: (tap, kc) and its linear index within the tile
     int es;              // bytes per input element (4: fp32, 2: bf16)
 };
@@ -158,18 +157,6 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t x_rsrc(const TdnnArgs& a, cons
 
 template <bool GUARD, bool X3>
 __device__ __forceinline__ void advance(const TdnnArgs& a, Ctx& cx, int n_chunks) {
-    if (X3 && cx.itl + 1 < n_chunks && cx.term < 2) {
-        // bf16x3: same chunk again -- product 1 reads the lo plane of X, product 2 the hi plane (with
-        // the lo weights, which simply follow in the packed stream)
-        ++cx.itl;
-        ++cx.term;
-        cx.term_off = cx.term == 1 ? a.x_plane_bytes : 0;
-        return;
-    }
-    if (X3) {
-        cx.term = 0;
-        cx.term_off = 0;
-    }
     if (cx.itl + 1 < n_chunks) {
         // taps innermost: consecutive chunks re-read the same 128-byte slab of activation rows,
         // shifted by the dilation, while it is still in L2 (the packed weights follow this order)
@@ -207,30 +194,43 @@ __device__ __forceinline__ void advance(const TdnnArgs& a, Ctx& cx, int n_chunks
 #define XV_FRG_B(q_, f_, S_) \
     if constexpr (!INBF) { rg.fb_##f_ = *reinterpret_cast<const float4*>((S_) + b_rd + XV_KO(q_)); }
 // LDS stores of staging set n_ into LDS buffer n_
-// bf16x3: the third product of a chunk (x_hi * W_lo) reads the same activation chunk as the first
-// (x_hi * W_hi), which is still in this LDS buffer (the product in between used the other one), so
-// its global loads and LDS stores are skipped -- a third of the activation traffic.  `lst_on` is
-// taken before the chunk's advance(): the stream then points two chunks past the one being stored.
 #define XV_LST_A(i_, n_) \
-    if constexpr (G > i_) { if (lst_on) *reinterpret_cast<float4*>(smem + n_ * kStageFloats + st_off + i_ * 32 * kBK) = rg.sA##i_##_##n_; }
-#define XV_LST_B(j_, n_) \
-    if constexpr (!INBF) { *reinterpret_cast<float4*>(smem + n_ * kStageFloats + st_off + kBM * kBK + j_ * 32 * kBK) = rg.sB##j_##_##n_; }
-// global loads of the chunk cx points at into staging set n_
-#define XV_GLD_A(i_, n_)                                                                                  \
-    if constexpr (G > i_) if (!(X3 && cx.term == 2)) {                                                    \
+    if constexpr (G > i_) { *reinterpret_cast<float4*>(smem + n_ * kStageFloats + st_off + i_ * 32 * kBK) = rg.sA##i_##_##n_; }
+// the second half of an LDS buffer: fp32 -> the weight tile; bf16x3 -> the lo plane of the
+// activation tile (same rows, x_plane_bytes further on in global memory); plain bf16 -> unused
+#define XV_LST_B(j_, n_)                                                                                  \
+    if constexpr (X3) {                                                                                   \
+        if constexpr (G > j_) *reinterpret_cast<float4*>(smem + n_ * kStageFloats + st_off + kBM * kBK + j_ * 32 * kBK) = rg.sB##j_##_##n_; \
+    } else if constexpr (!INBF) {                                                                         \
+        *reinterpret_cast<float4*>(smem + n_ * kStageFloats + st_off + kBM * kBK + j_ * 32 * kBK) = rg.sB##j_##_##n_; \
+    }
+// bf16x3 keeps ONE staging set (its chunks are three times as long, so one chunk of lead hides the
+// loads, and the registers are needed for the lo-plane fragments): set 0 -> LDS buffer b_
+#define XV_LST3(i_, b_)                                                                                   \
+    if constexpr (G > i_) {                                                                               \
+        *reinterpret_cast<float4*>(smem + b_ * kStageFloats + st_off + i_ * 32 * kBK) = rg.sA##i_##_0;      \
+        *reinterpret_cast<float4*>(smem + b_ * kStageFloats + st_off + kBM * kBK + i_ * 32 * kBK) = rg.sB##i_##_0; \
+    }
+// global loads of the chunk cx points at into staging set n_ (P_OFF: byte offset of the plane)
+#define XV_GLD_X(dst_, i_, P_OFF)                                                                         \
+    {                                                                                                     \
         const int row_shift = cx.tap * a.tap_rows;                                                        \
-        const int soff = ((row_shift + 32 * i_) * a.ldx + cx.kc * BKE) * ES + (X3 ? cx.term_off : 0);     \
+        const int soff = ((row_shift + 32 * i_) * a.ldx + cx.kc * BKE) * ES + (P_OFF);                    \
         if (GUARD) {                                                                                      \
             /* K past the layer's width (the folded taps of the next frame): an offset the descriptor's   \
                range check rejects, so the piece reads as zeros; rows past the tensor: same check */      \
             const int voff = (cx.kc * BKE + c * (16 / ES) < a.kpt) ? cx.xo##i_ : 0x7ffffff0;              \
-            rg.sA##i_##_##n_ = buf_load16(cx.xrsrc, voff, soff);                                             \
+            dst_ = buf_load16(cx.xrsrc, voff, soff);                                                      \
         } else {                                                                                          \
-            rg.sA##i_##_##n_ = buf_load16(cx.xrsrc, cx.xo##i_, soff);                                        \
+            dst_ = buf_load16(cx.xrsrc, cx.xo##i_, soff);                                                 \
         }                                                                                                 \
     }
+#define XV_GLD_A(i_, n_) \
+    if constexpr (G > i_) XV_GLD_X(rg.sA##i_##_##n_, i_, 0)
 #define XV_GLD_B(j_, n_)                                                                                  \
-    if constexpr (!INBF) {                                                                                \
+    if constexpr (X3) {                                                                                   \
+        if constexpr (G > j_) XV_GLD_X(rg.sB##j_##_##n_, j_, a.x_plane_bytes)                             \
+    } else if constexpr (!INBF) {                                                                         \
         rg.sB##j_##_##n_ = buf_load16(cx.wrsrc, cx.w_toff, (32 * j_ * a.k_pad + cx.itl * BKE) * ES);         \
     }
 // bf16: the weights are packed fragment-major at load time (pack.hip): for a 32-channel column
@@ -238,11 +238,24 @@ __device__ __forceinline__ void advance(const TdnnArgs& a, Ctx& cx, int n_chunks
 // wave reads its own B fragments straight into registers, one coalesced buffer load per k-step;
 // LDS carries only the activations.  Fragment q (k-step q of a 64-wide chunk) of chunk c_ -> set s_.
 #define XV_GLB(q_, s_, c_)                                                                                \
-    if constexpr (INBF) {                                                                                 \
+    if constexpr (INBF && !X3) {                                                                          \
         int cw_ = (c_);                                                                                   \
         if (cw_ >= n_chunks) cw_ -= n_chunks;                                                             \
         rg.gb##q_##_##s_ = buf_load16(cx.wfrsrc, cx.wf_voff, (4 * cw_ + q_) * 1024);                      \
     }
+// bf16x3: per chunk the stream holds the four W_hi k-step blocks, then the four W_lo blocks; both
+// fragments of k-step q_ of chunk c_ go to ONE register pair (gb<q>_0 = hi, gb<q>_1 = lo), reloaded
+// as soon as the k-step's last MFMA has issued (three quarters of a chunk ahead of their use)
+#define XV_GLB3(q_, c_)                                                                                   \
+    if constexpr (X3) {                                                                                   \
+        int cw_ = (c_);                                                                                   \
+        if (cw_ >= n_chunks) cw_ -= n_chunks;                                                             \
+        rg.gb##q_##_0 = buf_load16(cx.wfrsrc, cx.wf_voff, (8 * cw_ + q_) * 1024);                         \
+        rg.gb##q_##_1 = buf_load16(cx.wfrsrc, cx.wf_voff, (8 * cw_ + 4 + q_) * 1024);                     \
+    }
+// bf16x3: lo-plane fragment of k-step q_ (second half of the LDS buffer) -> fragment set 1
+#define XV_FRG_L(i_, q_, S_) \
+    if constexpr (G > i_) { rg.fa##i_##_1 = *reinterpret_cast<const float4*>((S_) + kBM * kBK + a_rd + i_ * 32 * kBK + XV_KO(q_)); }
 #define XV_GLD_ALL(n_) XV_GLD_A(0, n_) XV_GLD_A(1, n_) XV_GLD_A(2, n_) XV_GLD_A(3, n_) \
                        XV_GLD_B(0, n_) XV_GLD_B(1, n_) XV_GLD_B(2, n_) XV_GLD_B(3, n_)
 #define XV_LST_ALL(n_) XV_LST_A(0, n_) XV_LST_A(1, n_) XV_LST_A(2, n_) XV_LST_A(3, n_) \
@@ -274,6 +287,15 @@ __device__ __forceinline__ void advance(const TdnnArgs& a, Ctx& cx, int n_chunks
         XV_MF(0, z, f_, s8) XV_MF(1, z, f_, s9) XV_MF(2, z, f_, s10) XV_MF(3, z, f_, s11)                 \
         XV_MF(0, w, f_, s12) XV_MF(1, w, f_, s13) XV_MF(2, w, f_, s14) XV_MF(3, w, f_, s15)               \
     }
+// bf16x3: four MFMAs (row groups) of fragment set f_ against B register b_, one slot behind each
+#define XV_M3(i_, f_, b_)                                                                                 \
+    if constexpr (G > i_) {                                                                               \
+        acc##i_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, rg.fa##i_##_##f_),   \
+                                                          __builtin_bit_cast(bf16x8, rg.b_), acc##i_, 0, 0, 0); \
+    }                                                                                                     \
+    SB();
+#define XV_G3(f_, b_, s0, s1, s2, s3) \
+    XV_M3(0, f_, b_) s0 SB(); XV_M3(1, f_, b_) s1 SB(); XV_M3(2, f_, b_) s2 SB(); XV_M3(3, f_, b_) s3 SB();
 #define XV_NOP ;
 // One K-chunk held in LDS buffer P_; N_ = the other buffer = the staging set holding chunk it+1.
 // Branch-free: the last chunk of a tile also stores/loads/reads ahead (clamped to the last
@@ -282,7 +304,6 @@ __device__ __forceinline__ void advance(const TdnnArgs& a, Ctx& cx, int n_chunks
 #define XV_ADVANCE (advance<GUARD, X3>)(a, cx, n_chunks);
 #define XV_CHUNK(P_, N_, IT_)                                                                             \
     {                                                                                                     \
-        const bool lst_on = !(X3 && cx.term == 0);                                                        \
         const float* S = smem + P_ * kStageFloats;                                                        \
         const float* Sn = smem + N_ * kStageFloats;                                                       \
         XV_KG(0, P_, 0, XV_FRG_A(0, 1, 1, S), XV_FRG_A(1, 1, 1, S), XV_FRG_A(2, 1, 1, S),                 \
@@ -304,6 +325,36 @@ __device__ __forceinline__ void advance(const TdnnArgs& a, Ctx& cx, int n_chunks
               XV_NOP, XV_NOP, XV_NOP, XV_NOP, XV_NOP, XV_NOP, XV_NOP, XV_NOP)                             \
     }
 
+// bf16x3: one K-chunk = [hi tile | lo tile] in LDS buffer P_.  Per k-step q: x_hi*W_hi (hi frags in
+// set 0, read during the previous k-step), x_hi*W_lo, x_lo*W_hi (lo frags into set 1 during the first
+// group) -- 12 MFMAs per k-step, 48 per chunk and barrier; every fragment read and every weight
+// fragment load feeds its MFMAs once, the staging of chunk it+1 / it+2 rides in the middle groups.
+#define XV_CHUNK3(P_, N_, IT_)                                                                            \
+    {                                                                                                     \
+        const float* S = smem + P_ * kStageFloats;                                                        \
+        const float* Sn = smem + N_ * kStageFloats;                                                       \
+        XV_G3(0, gb0_0, XV_FRG_L(0, 0, S), XV_FRG_L(1, 0, S), XV_FRG_L(2, 0, S), XV_FRG_L(3, 0, S))       \
+        XV_G3(0, gb0_1, XV_LST3(0, N_), XV_LST3(1, N_), XV_LST3(2, N_), XV_LST3(3, N_))                   \
+        XV_G3(1, gb0_0, XV_FRG_A(0, 1, 0, S), XV_FRG_A(1, 1, 0, S), XV_FRG_A(2, 1, 0, S),                 \
+              XV_FRG_A(3, 1, 0, S))                                                                       \
+        XV_ADVANCE                                                                                        \
+        XV_G3(0, gb1_0, XV_FRG_L(0, 1, S), XV_FRG_L(1, 1, S), XV_FRG_L(2, 1, S), XV_FRG_L(3, 1, S))       \
+        XV_G3(0, gb1_1, XV_GLB3(0, (IT_) + 1), XV_GLD_A(0, 0) XV_GLD_A(1, 0),                             \
+              XV_GLD_A(2, 0) XV_GLD_A(3, 0), XV_GLD_B(0, 0) XV_GLD_B(1, 0))                               \
+        XV_G3(1, gb1_0, XV_FRG_A(0, 2, 0, S), XV_FRG_A(1, 2, 0, S), XV_FRG_A(2, 2, 0, S),                 \
+              XV_FRG_A(3, 2, 0, S))                                                                       \
+        XV_G3(0, gb2_0, XV_FRG_L(0, 2, S), XV_FRG_L(1, 2, S), XV_FRG_L(2, 2, S), XV_FRG_L(3, 2, S))       \
+        XV_G3(0, gb2_1, XV_GLB3(1, (IT_) + 1), XV_GLD_B(2, 0) XV_GLD_B(3, 0), XV_NOP, XV_NOP)             \
+        XV_G3(1, gb2_0, XV_FRG_A(0, 3, 0, S), XV_FRG_A(1, 3, 0, S), XV_FRG_A(2, 3, 0, S),                 \
+              XV_FRG_A(3, 3, 0, S))                                                                       \
+        XV_G3(0, gb3_0, XV_FRG_L(0, 3, S), XV_FRG_L(1, 3, S), XV_FRG_L(2, 3, S), XV_FRG_L(3, 3, S))       \
+        XV_G3(0, gb3_1, XV_GLB3(2, (IT_) + 1), XV_NOP, XV_NOP, XV_NOP)                                    \
+        __syncthreads(); /* chunk it+1 complete in LDS; chunk it's buffer is free */                     \
+        XV_G3(1, gb3_0, XV_FRG_A(0, 0, 0, Sn), XV_FRG_A(1, 0, 0, Sn), XV_FRG_A(2, 0, 0, Sn),              \
+              XV_FRG_A(3, 0, 0, Sn))                                                                      \
+        XV_GLB3(3, (IT_) + 1)                                                                             \
+    }
+
 // Pipeline registers that live across tiles: two staging sets (_0/_1: A row groups 0..3 and W
 // row blocks 0..3 of a chunk in flight) and two fragment sets.  A struct of named members, not
 // arrays (see above).
@@ -320,27 +371,36 @@ struct Lane {
 };
 
 // Once per block: chunk 0 of the first tile -> LDS buffer 0, its first fragments -> set 0,
-// chunks 1 and 2 in flight in the two staging sets.
+// chunks 1 and 2 in flight in the two staging sets (bf16x3: chunk 1 in its single set).
 template <bool GUARD, bool INBF, bool X3>
 __device__ __forceinline__ void block_prologue(const TdnnArgs& a, float* smem, Ctx& cx, Regs& rg, const Lane& ln,
                                                int n_chunks) {
     constexpr int G = 4;   // fetch all four row groups: rows past a short first tile are allocated
     constexpr int ES = INBF ? 2 : 4, BKE = 128 / ES;
     const int h = ln.h, sw = ln.sw, a_rd = ln.a_rd, b_rd = ln.b_rd, st_off = ln.st_off, c = ln.c;
-    constexpr bool lst_on = true;
-    XV_GLD_ALL(0)
-    advance<GUARD, X3>(a, cx, n_chunks);
-    XV_GLD_ALL(1)
-    SB();
-    XV_LST_ALL(0)
-    SB();
-    advance<GUARD, X3>(a, cx, n_chunks);
-    XV_GLD_ALL(0)
+    if constexpr (X3) {      // one staging set: chunk 0 -> LDS buffer 0, chunk 1 in flight in the set
+        XV_GLD_ALL(0)
+        SB();
+        XV_LST3(0, 0) XV_LST3(1, 0) XV_LST3(2, 0) XV_LST3(3, 0)
+        SB();
+        advance<GUARD, X3>(a, cx, n_chunks);
+        XV_GLD_ALL(0)
+    } else {
+        XV_GLD_ALL(0)
+        advance<GUARD, X3>(a, cx, n_chunks);
+        XV_GLD_ALL(1)
+        SB();
+        XV_LST_ALL(0)
+        SB();
+        advance<GUARD, X3>(a, cx, n_chunks);
+        XV_GLD_ALL(0)
+    }
     __syncthreads();
     XV_FRG_A(0, 0, 0, smem) XV_FRG_A(1, 0, 0, smem) XV_FRG_A(2, 0, 0, smem) XV_FRG_A(3, 0, 0, smem)
     XV_FRG_B(0, 0, smem)
     XV_GLB(0, 0, 0) XV_GLB(1, 0, 0) XV_GLB(2, 0, 0) XV_GLB(3, 0, 0)
     XV_GLB(0, 1, 1) XV_GLB(1, 1, 1) XV_GLB(2, 1, 1) XV_GLB(3, 1, 1)
+    XV_GLB3(0, 0) XV_GLB3(1, 0) XV_GLB3(2, 0) XV_GLB3(3, 0)
     SB();
 }
 
@@ -362,8 +422,13 @@ __device__ __forceinline__ void process_tile(const TdnnArgs& a, float* smem, Ctx
 #endif
     // ---- K chunks, two per trip (LDS buffer 0 then 1); n_chunks is even
     for (int it = 0; it < n_chunks; it += 2) {
-        XV_CHUNK(0, 1, it)
-        XV_CHUNK(1, 0, it + 1)
+        if constexpr (X3) {
+            XV_CHUNK3(0, 1, it)
+            XV_CHUNK3(1, 0, it + 1)
+        } else {
+            XV_CHUNK(0, 1, it)
+            XV_CHUNK(1, 0, it + 1)
+        }
     }
 #ifdef XVEC_DIAG
     SB();
@@ -465,7 +530,7 @@ __global__ __launch_bounds__(256, 2) void tdnn_kernel(const TdnnArgs a) {
         g_end = a.groups_total * (int64_t)(p + 1) / a.blocks_per_col;
     }
     const int n0 = j * kBN;
-    const int n_chunks = a.n_taps * a.cpt * (X3 ? 3 : 1);
+    const int n_chunks = a.n_taps * a.cpt;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -511,8 +576,6 @@ __global__ __launch_bounds__(256, 2) void tdnn_kernel(const TdnnArgs a) {
     cx.tap = 0;
     cx.kc = 0;
     cx.itl = 0;
-    cx.term = 0;
-    cx.term_off = 0;
 
     Regs rg;
     block_prologue<GUARD, INBF, X3>(a, smem, cx, rg, ln, n_chunks);
@@ -557,7 +620,7 @@ extern "C" int xvec_diag_read(unsigned long long* host, int n_words) {
 hipError_t launch_tdnn(const TdnnArgs& a, TdnnVariant v, hipStream_t s) {
     if (a.groups_total <= 0 || a.blocks_per_col <= 0 || a.blocks_per_col > a.groups_total || (a.cpt & 1))
         return hipErrorInvalidValue;
-    const bool x3 = a.terms == 3;     // bf16x3: compile-time mode of the bf16 instantiations
+    const bool x3 = a.terms == 2;     // bf16x3: compile-time mode of the bf16 instantiations
     switch (v) {
         case TdnnVariant::kF32First: return launch_variant<true, false, true, false, false>(a, s);
         case TdnnVariant::kF32: return launch_variant<false, false, true, false, false>(a, s);

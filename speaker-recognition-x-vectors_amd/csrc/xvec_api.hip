@@ -47,7 +47,7 @@ struct xvec_handle {
     TdnnGeom geo[XVEC_NUM_TDNN];
     TdnnGeom geo16[XVEC_NUM_TDNN];     // bf16 packing of layers 2-5: 64-element chunks (layer 1 stays fp32)
     void* Wp16[XVEC_NUM_TDNN];         // bf16, fragment-major
-    void* Wp48[XVEC_NUM_TDNN];         // bf16x3: the hi/hi/lo chunk stream (3x the size), fragment-major
+    void* Wp48[XVEC_NUM_TDNN];         // bf16x3: per chunk W_hi then W_lo fragments (2x the size), fragment-major
     float* Wp[XVEC_NUM_TDNN];
     float* vec[XVEC_NUM_TDNN];         // bias | scale | shift, n_pad each
     bool tdnn_loaded[XVEC_NUM_TDNN];
@@ -195,9 +195,9 @@ int run_tdnn(xvec_handle* h, int layer, TdnnVariant v, const void* X, int ldx, i
     if (x3) {
         if (x_plane > 0x3fffffff || y_plane > 0x3fffffff)
             return fail(XVEC_ERR_ARG, "batch too large for bf16x3 (plane offsets must fit 30 bits); split it");
-        a.terms = 3;
+        a.terms = 2;
         a.Wf = h->Wp48[layer];
-        a.k_pad = 3 * g.k_pad;
+        a.k_pad = 2 * g.k_pad;
         a.x_plane_bytes = (int)x_plane;
         a.y_plane_bytes = (int)y_plane;
         a.x_bytes = x_rows > 0 ? x_plane + x_rows * (int64_t)ldx * 2 : 0;
@@ -377,7 +377,7 @@ int xvec_create(const xvec_cfg* cfg, xvec_handle** out) {
     for (int i = 0; i < XVEC_NUM_TDNN; ++i) {
         const TdnnGeom& g = h->geo[i];
         if (hipMalloc(&h->Wp16[i], (size_t)h->geo16[i].n_pad * h->geo16[i].k_pad * 2) != hipSuccess ||
-            hipMalloc(&h->Wp48[i], (size_t)h->geo16[i].n_pad * h->geo16[i].k_pad * 2 * 3) != hipSuccess ||
+            hipMalloc(&h->Wp48[i], (size_t)h->geo16[i].n_pad * h->geo16[i].k_pad * 2 * 2) != hipSuccess ||
             hipMalloc(reinterpret_cast<void**>(&h->Wp[i]), (size_t)g.n_pad * g.k_pad * 4) != hipSuccess ||
             hipMalloc(reinterpret_cast<void**>(&h->vec[i]), (size_t)3 * g.n_pad * 4) != hipSuccess) {
             xvec_destroy(h);
@@ -443,7 +443,7 @@ int xvec_load_tdnn(xvec_handle* h, int layer, const float* weight, const float* 
     HIP_TRY(launch_pack_tdnn_bf16(weight, h->geo16[layer], h->Wp16[layer], static_cast<hipStream_t>(stream)));
     {
         TdnnGeom g3 = h->geo16[layer];
-        g3.terms = 3;
+        g3.terms = 2;
         HIP_TRY(launch_pack_tdnn_bf16(weight, g3, h->Wp48[layer], static_cast<hipStream_t>(stream)));
     }
     h->tdnn_loaded[layer] = true;

@@ -59,7 +59,7 @@ struct TdnnGeom {
     int src_taps;       // taps in the PyTorch weight
     int src_cin;        // channels per tap in the PyTorch weight
     int chunk_k;        // K elements per 128-byte chunk (32 fp32, 64 bf16): unit of the packed K order
-    int terms;          // bf16x3 weight stream: 3 (chunk walked as hi, hi, lo), else 1
+    int terms;          // bf16x3 weight stream: 2 (per chunk: W_hi blocks, W_lo blocks), else 1
 };
 
 struct TdnnArgs {
@@ -83,9 +83,9 @@ struct TdnnArgs {
     // fused statistics-pooling epilogue (layer 5)
     float* pool_part;         // [slots][2][n_pad] (mean, M2) per (32-row group, utterance)
     // bf16x3 (fp32 values carried as two bf16 planes hi + lo, three bf16 products per k-step:
-    // x_hi*W_hi + x_lo*W_hi + x_hi*W_lo).  terms == 3: every K chunk is walked three times, the second
-    // time from the lo plane of X (x_plane_bytes further on); Wf holds the matching weight stream.
-    int terms;                // 1 (plain) or 3
+    // x_hi*W_hi + x_hi*W_lo + x_lo*W_hi).  terms == 2: X has a lo plane x_plane_bytes after the hi
+    // plane and Wf holds, per chunk, the W_hi fragments followed by the W_lo fragments.
+    int terms;                // 1 (plain) or 2
     int x_plane_bytes;        // byte distance from the hi plane of X to its lo plane
     int y_plane_bytes;        // > 0: bf16 output as two planes, lo plane this many bytes after Y
     int64_t x_bytes;          // guarded variant: readable bytes from X (0: x_rows * ldx * element size)

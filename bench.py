@@ -260,10 +260,11 @@ def main():
         traffic, traffic_src = None, None
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-            key = {"fp32": "tdnn_kernel<false, false, true, false, false>",
-                   "bf16": "tdnn_kernel<false, false, true, true, true>"}[args.dtype]   # bf16x3: no PMC pass yet
+            key = {"fp32": "tdnn_kernel<false, false, true, false, false",
+                   "bf16": "tdnn_kernel<false, false, true, true, true"}[args.dtype]   # bf16x3: no PMC pass yet
+            key = next(k for k in tj if k.startswith(key) and not k.rstrip(">").endswith(", true, true, true, true"))
             traffic, traffic_src = tj[key]["hbm_bytes_per_launch"], tj["source"]
-        except (OSError, KeyError, ValueError):
+        except (OSError, KeyError, ValueError, StopIteration):
             pass
         out = {
             "metric": "x-vector embeddings/sec (300-frame utt)", "value": round(value, 1), "unit": "embeddings/s",

@@ -63,7 +63,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--frames", type=int, default=300)
-    ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU-baseline work (0 = skip)")
+    ap.add_argument("--cpu-budget", type=float, default=40.0,
+                    help="seconds of CPU-baseline work over its four legs (B=1/64 x all cores/1 thread; 0 = skip)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the secondary legs of the default line (configs[4] bf16 and configs[2] ragged figures)")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="initialise the RCCL process group and run the all-gather leg even with one rank "
+                         "(one-GPU rehearsal of the N>1 code path)")
     ap.add_argument("--dtype", choices=("fp32", "bf16", "bf16x3"), default="fp32",
                     help="frame-level arithmetic; the headline (BASELINE configs[1]) is fp32 (exact fp32 MFMA).  "
                          "bf16x3: fp32 values as two bf16 planes, three bf16 products per k-step (parity bar 1e-4)")
@@ -88,8 +94,12 @@ def main():
     import xvector_amd as xa
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    collective = world > 1 or args.force_collective
+    if collective:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
 
     B, T, K, W = args.batch, args.frames, args.steps, args.warmup
@@ -114,7 +124,7 @@ def main():
     if lengths is not None:
         x *= (torch.arange(T, device=dev)[None, :] < torch.tensor(lengths, device=dev)[:, None])[:, :, None]
     emb = torch.empty((K * B, 512), device=dev, dtype=torch.float32) if n_local is None else None
-    gathered = torch.empty((world * K * B, 512), device=dev, dtype=torch.float32) if world > 1 and n_local is None else None
+    gathered = torch.empty((world * K * B, 512), device=dev, dtype=torch.float32) if collective and n_local is None else None
 
     waves = fe = None
     if args.workload == "wave":
@@ -134,19 +144,20 @@ def main():
         return xa.extract.extract_sharded(
             model.extract_x_vec,
             lambda lo, hi: torch.randn((hi - lo, T, 24), generator=gen, device=dev, dtype=torch.float32),
-            args.utterances, batch_size=B)
+            args.utterances, batch_size=B, force_collective=args.force_collective)
 
     def barrier():
-        if world > 1:
+        if collective:
             dist.barrier()
 
     for _ in range(W):
         model.extract_x_vec(x, lengths=lengths)
-    if world > 1:   # warm the collective too (communicator setup is not part of a step)
+    if collective:   # warm the collective too (communicator setup is not part of a step)
         if n_local is None:
             dist.all_gather_into_tensor(gathered, emb)
         else:
-            xa.extract.gather_embeddings(torch.zeros((n_local, 512), device=dev), args.utterances)
+            xa.extract.gather_embeddings(torch.zeros((n_local, 512), device=dev), args.utterances,
+                                         force=args.force_collective)
     torch.cuda.synchronize(dev)
     barrier()
     torch.cuda.synchronize(dev)
@@ -157,13 +168,13 @@ def main():
     else:
         for k in range(K):
             step(k)
-        if world > 1:
+        if collective:
             dist.all_gather_into_tensor(gathered, emb)
     torch.cuda.synchronize(dev)
     barrier()
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
-    if world > 1:
+    if collective:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -209,23 +220,81 @@ def main():
             torch.cuda.synchronize(dev)
             dt_graph = time.perf_counter() - t3
 
-    if world == 1:
+    if world == 1 and not args.force_collective:
         try:
             extras()
         except Exception as e:      # noqa: BLE001
             print(f"bench.py: extras skipped ({type(e).__name__}: {e})", file=sys.stderr, flush=True)
 
     # ---- per-kernel durations: hipEvents recorded by the library on the launch stream -----
-    model.set_profiling(True, dev)
     names = ("tdnn1", "tdnn2", "tdnn3", "tdnn4", "tdnn5_pool", "pool_finalize", "segment6")
-    acc = {n: 0.0 for n in names}
-    for _ in range(min(K, 50)):
-        model.extract_x_vec(x, lengths=lengths)
-        tm = model.timings_ms(dev)       # synchronises on the step's last event
-        for n in names:
-            acc[n] += tm[n]
-    model.set_profiling(False, dev)
-    avg_ms = {n: acc[n] / min(K, 50) for n in names}
+
+    def per_kernel_ms(mdl, xin, lens, n_iter):
+        mdl.set_profiling(True, dev)
+        acc = {n: 0.0 for n in names}
+        for _ in range(n_iter):
+            mdl.extract_x_vec(xin, lengths=lens)
+            tm = mdl.timings_ms(dev)       # synchronises on the step's last event
+            for n in names:
+                acc[n] += tm[n]
+        mdl.set_profiling(False, dev)
+        return {n: acc[n] / n_iter for n in names}
+
+    avg_ms = per_kernel_ms(model, x, lengths, min(K, 50))
+
+    # ---- secondary legs of the default line (never `value`): the other single-GPU BASELINE configs measured
+    # in the same driver run -- configs[4] (the same batch in bf16) and configs[2] (ragged 200-1000 frames)
+    secondary = {}
+
+    def secondary_legs():
+        K2 = min(K, 50)
+        m16 = xa.XVectorModel(precision="bf16")
+        m16.load_state_dict(sd)
+        m16 = m16.to(dev).eval()
+        for _ in range(5):
+            m16.extract_x_vec(x)
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for _ in range(K2):
+            m16.extract_x_vec(x)
+        torch.cuda.synchronize(dev)
+        d16 = time.perf_counter() - t1
+        ms16 = per_kernel_ms(m16, x, None, min(K2, 20))
+        lf16 = [f * B for f in layer_flops(T)]
+        dom16 = (lf16[1] + lf16[2] + lf16[3]) / ((ms16["tdnn2"] + ms16["tdnn3"] + ms16["tdnn4"]) * 1e-3)
+        secondary.update({
+            "bf16_embeddings_per_s": round(K2 * B / d16, 1), "bf16_ms_per_step": round(d16 / K2 * 1e3, 4),
+            "bf16_dominant_tflops": round(dom16 / 1e12, 1), "bf16_roofline_frac": round(dom16 / BF16_MFMA_PEAK, 4),
+            "bf16_path_flop_frac_of_peak": round(K2 * B / d16 * total_flops(T) / BF16_MFMA_PEAK, 4),
+            "bf16_path_hbm_frac_algorithmic": round(K2 * B / d16 * BYTES_PER_UTT * T / 300.0 * 0.5 / HBM_PEAK, 4),
+            "bf16_per_kernel_ms": {n: round(v, 4) for n, v in ms16.items()}})
+        del m16
+        lens_np = xa.synth.make_lengths(B)
+        Tr = int(lens_np.max())
+        xr = torch.randn((B, Tr, 24), generator=gen, device=dev, dtype=torch.float32)
+        xr *= (torch.arange(Tr, device=dev)[None, :] < torch.tensor(lens_np, device=dev)[:, None])[:, :, None]
+        ll = lens_np.tolist()
+        K3 = min(K, 20)
+        for _ in range(3):
+            model.extract_x_vec(xr, lengths=ll)
+        torch.cuda.synchronize(dev)
+        t2 = time.perf_counter()
+        for _ in range(K3):
+            model.extract_x_vec(xr, lengths=ll)
+        torch.cuda.synchronize(dev)
+        dr = time.perf_counter() - t2
+        secondary.update({
+            "ragged_utt_per_s": round(K3 * B / dr, 1), "ragged_valid_frames_per_s": round(K3 * int(lens_np.sum()) / dr, 1),
+            "ragged_ms_per_step": round(dr / K3 * 1e3, 4), "ragged_valid_frames_per_batch": int(lens_np.sum()),
+            "ragged_workload": f"configs[2]: batch={B} utterances of 200-1000 frames (numpy default_rng(1234)), zero-padded "
+                               f"to {Tr} with a lengths mask, fp32"})
+
+    if (world == 1 and not args.force_collective and not args.no_secondary and args.workload == "fixed"
+            and args.dtype == "fp32"):
+        try:
+            secondary_legs()
+        except Exception as e:      # noqa: BLE001
+            print(f"bench.py: secondary legs skipped ({type(e).__name__}: {e})", file=sys.stderr, flush=True)
 
     if rank == 0:
         act_bytes_scale = 0.5 if args.dtype == "bf16" else 1.0     # bf16x3 moves two bf16 planes = fp32 bytes
@@ -286,7 +355,8 @@ def main():
                        "pcie_inclusive_overlapped_embeddings_per_s_per_gpu":
                            round(K_pcie * B / dt_pcie_ovl, 1) if dt_pcie_ovl else None,
                        "sharding": f"utterance-sharded x{world}"
-                       + (", one all-gather of [K*B,512] fp32 in the timed region" if world > 1 else "")},
+                       + (", one all-gather of [K*B,512] fp32 in the timed region" if collective else ""),
+                       **secondary},
             "roofline": {
                 "bound": "mfma", "kernel": dom_kernel,
                 "achieved": round(achieved, 2), "peak": peak / 1e12, "unit": "TFLOP/s",
@@ -303,14 +373,19 @@ def main():
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import xvector_oracle as oracle
             p = {k: v for k, v in sd.items() if v.is_floating_point()}
-            eps, threads, n_utts, secs = oracle.time_cpu_baseline(p, T=T, batch=64, budget_s=args.cpu_budget,
-                                                                  threads=usable_cpus())
-            out["cpu_baseline"] = {"value": round(eps, 1), "unit": "embeddings/s", "cores": threads, "kind": "port",
-                                   "sample": f"{n_utts} utterances of {T} frames in batches of 64, fp32, "
-                                             f"{secs:.1f} s of oracle/xvector_oracle.py (PyTorch CPU restatement of "
-                                             "the reference's op sequence)"}
+            legs = oracle.time_cpu_baseline(p, T=T, budget_s=args.cpu_budget, threads=usable_cpus())
+            head = legs["b64_all"]
+            secs = sum(l["seconds"] for l in legs.values())
+            out["cpu_baseline"] = {
+                "value": head["embeddings_per_s"], "unit": "embeddings/s", "cores": head["threads"], "kind": "port",
+                "sample": f"{T}-frame utterances, fp32, oracle/xvector_oracle.py (PyTorch CPU restatement of the "
+                          f"reference's op sequence), SURVEY 8(d) protocol: B=64 and B=1, {head['threads']} threads and 1 "
+                          f"thread, 3 warm-ups + median of 10 per leg (a leg that would not fit its share of the "
+                          f"{args.cpu_budget:.0f} s budget is cut to 1 warm-up + >=3 timed passes: see legs.*.reps); "
+                          f"value = B=64 on all {head['threads']} usable cores; {secs:.1f} s of CPU work in all",
+                "legs": legs}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if collective:
         dist.destroy_process_group()
 
 

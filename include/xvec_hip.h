@@ -10,8 +10,17 @@
  *   - every tensor pointer is a DEVICE pointer (HIP) unless the name ends in _host;
  *   - tensors are contiguous, batch-first, time-major, channels-last, fp32 -- exactly the
  *     [B,T,C] layout the reference feeds (main.py:99,137);
- *   - all work is enqueued on the caller's stream and is asynchronous w.r.t. the host;
- *     nothing allocates device memory after xvec_create;
+ *   - all work is enqueued on the caller's stream and is asynchronous w.r.t. the host; nothing
+ *     allocates device or pinned memory after xvec_create (the fixed-length path is therefore
+ *     capturable into a hipGraph).  What is synchronous: xvec_create / xvec_destroy; xvec_get_timings
+ *     (waits for the last recorded event); and the ragged entry points (lengths_host / offsets_host
+ *     given) copy the offsets through a ring of two pinned staging slots owned by the handle, so
+ *     only a third ragged call issued before the first one's offset copy has run waits for that copy;
+ *   - every entry point that takes a handle runs on the handle's device and leaves the calling
+ *     thread's current device as it found it (xvec_create included);
+ *   - limits: at most 65535 utterances per call; input_size, hidden_size <= 8192; rows are addressed
+ *     with 32-bit byte offsets, so (utterances x context + 136) x channels x element size must stay
+ *     below 2^31 (XVEC_ERR_ARG otherwise -- split the batch);
  *   - every function returns XVEC_OK (0) or an error code and never throws; the message
  *     for the last error on the calling thread is available from xvec_last_error();
  *   - one handle per device; distinct handles may be used from distinct threads.

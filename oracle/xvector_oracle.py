@@ -129,23 +129,50 @@ def flops_per_utt(T: int, layer: int = 6) -> int:
     return f
 
 
-def time_cpu_baseline(p: Dict[str, torch.Tensor], T: int = 300, batch: int = 64,
-                      budget_s: float = 15.0, threads: Optional[int] = None, seed: int = 0):
-    """Time this oracle (the reference's op sequence on the host CPU, fp32) on a bounded
-    sample: repeat `batch`-utterance passes until ~budget_s seconds of CPU work.
-    Returns (embeddings_per_s, n_threads, n_utts_timed, seconds)."""
-    if threads is not None:
-        torch.set_num_threads(threads)
-    g = torch.Generator().manual_seed(seed)
-    x = torch.randn(batch, T, 24, generator=g, dtype=torch.float32)
+def _time_leg(p, x, threads: int, budget_s: float, warmups: int = 3, reps: int = 10):
+    """One leg of the protocol: `warmups` untimed passes, then the MEDIAN of `reps` timed passes over
+    the batch x with torch.set_num_threads(threads).  When warmups + reps passes would not fit
+    budget_s (estimated from the first pass), the leg is cut to 1 warm-up and >= 3 timed passes and
+    says so in its record."""
+    torch.set_num_threads(threads)
     with torch.no_grad():
-        extract_x_vec(x[:2], p)                       # warm-up (thread pool, allocator)
         t0 = time.perf_counter()
-        n = 0
-        while True:
+        extract_x_vec(x, p)                           # first pass: warm-up #1 and the cost estimate
+        est = time.perf_counter() - t0
+        if est * (warmups + reps) > budget_s:
+            warmups, reps = 1, max(3, min(reps, int(budget_s / max(est, 1e-9)) - 1))
+        for _ in range(warmups - 1):
             extract_x_vec(x, p)
-            n += batch
-            dt = time.perf_counter() - t0
-            if dt >= budget_s:
-                break
-    return n / dt, torch.get_num_threads(), n, dt
+        times = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            extract_x_vec(x, p)
+            times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2] if len(times) % 2 else 0.5 * (times[len(times) // 2 - 1] + times[len(times) // 2])
+    B, T = x.shape[0], x.shape[1]
+    return {"batch": B, "threads": torch.get_num_threads(), "warmups": warmups, "reps": reps,
+            "median_ms": round(med * 1e3, 3), "embeddings_per_s": round(B / med, 2),
+            "gflops": round(B * flops_per_utt(T) / med / 1e9, 1), "seconds": round(sum(times) + est * warmups, 2)}
+
+
+def time_cpu_baseline(p: Dict[str, torch.Tensor], T: int = 300, budget_s: float = 40.0,
+                      threads: Optional[int] = None, seed: int = 0):
+    """SURVEY.md 8(d) / BASELINE.md 4 protocol: this oracle (the reference's op sequence on the host
+    CPU, fp32) on identical synthetic inputs at B=1 and B=64, with n = `threads` (all usable cores)
+    and n = 1; 3 warm-ups + median of 10 per leg, each leg bounded to its share of budget_s (the
+    one-thread B=64 leg, by far the longest, gets 55 %).
+    Returns the four leg records, keyed "b64_all", "b1_all", "b64_1t", "b1_1t"."""
+    n_all = threads if threads is not None else torch.get_num_threads()
+    g = torch.Generator().manual_seed(seed)
+    x64 = torch.randn(64, T, 24, generator=g, dtype=torch.float32)
+    x1 = x64[:1].clone()
+    keep = torch.get_num_threads()
+    legs = {}
+    try:
+        for key, x, n, share in (("b64_all", x64, n_all, 0.35), ("b1_all", x1, n_all, 0.05), ("b1_1t", x1, 1, 0.05),
+                                 ("b64_1t", x64, 1, 0.55)):
+            legs[key] = _time_leg(p, x, n, budget_s * share)
+    finally:
+        torch.set_num_threads(keep)
+    return legs

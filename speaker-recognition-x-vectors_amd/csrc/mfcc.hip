@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "../../include/xvec_hip.h"
+#include "xvec_internal.h"
 
 namespace {
 
@@ -343,13 +344,9 @@ int xvec_mfcc(xvec_mfcc_plan* p, const float* signal, int32_t B, int64_t n_sampl
     const int per_wave = wave_floats(p->dev.nfft, p->dev.nbins);
     const size_t lds = ((size_t)per_wave * kWavesPerBlock + p->dev.table_floats) * 4;
     if (lds > 64 * 1024) {   // nfft 4096: opt in to the larger dynamic LDS once
-        static bool attr = false;
-        if (!attr) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(mfcc_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    160 * 1024) != hipSuccess)
-                return mfail(XVEC_ERR_HIP, "hipFuncSetAttribute failed");
-            attr = true;
-        }
+        static xvec::LdsOptIn opt;
+        if (opt.ensure(reinterpret_cast<const void*>(mfcc_kernel<0>), 160 * 1024) != hipSuccess)
+            return mfail(XVEC_ERR_HIP, "hipFuncSetAttribute failed");
     }
     const int grid_x = (n_frames + 2 * kWavesPerBlock - 1) / (2 * kWavesPerBlock);
     if (p->dev.log2n == 9)

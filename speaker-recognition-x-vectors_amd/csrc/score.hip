@@ -198,14 +198,10 @@ int gemm_nt(const double* A, int64_t lda, const double* B, int64_t ldb, int64_t 
     const size_t lds = (size_t)2 * (kSM + kSN) * kSLD * sizeof(double);
     const bool vec = (K % 2 == 0) && (lda % 2 == 0) && (ldb % 2 == 0) && (reinterpret_cast<uintptr_t>(A) % 16 == 0) &&
                      (reinterpret_cast<uintptr_t>(B) % 16 == 0);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_f64_kernel<true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_f64_kernel<false>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    static LdsOptIn opt_v, opt_s;
+    const hipError_t ea = vec ? opt_v.ensure(reinterpret_cast<const void*>(&gemm_nt_f64_kernel<true>), (int)lds)
+                              : opt_s.ensure(reinterpret_cast<const void*>(&gemm_nt_f64_kernel<false>), (int)lds);
+    if (ea != hipSuccess) return sfail(XVEC_ERR_HIP, "hipFuncSetAttribute failed: %s", hipGetErrorString(ea));
     if (vec)
         gemm_nt_f64_kernel<true><<<(unsigned)(tm * tn), 256, lds, s>>>(g);
     else

@@ -100,11 +100,11 @@ __device__ __forceinline__ void pool_group_impl(const TdnnArgs& a, const f32x16&
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            const float w = (float)((lm >> ((e & 3) + 8 * (e >> 2))) & 1u);
-            const float d = v[e] - c;
-            const float t = w * d;
-            s1 += t;
-            s2 = fmaf(t, d, s2);
+            // a SELECT, not a 0/1 weight: rows outside the utterance may be rows no layer wrote
+            // (the tail of the last 32-row group), and 0 * Inf would poison the sums
+            const float d = ((lm >> ((e & 3) + 8 * (e >> 2))) & 1u) ? v[e] - c : 0.f;
+            s1 += d;
+            s2 = fmaf(d, d, s2);
         }
         s1 = add_halves(s1);
         s2 = add_halves(s2);

@@ -599,13 +599,8 @@ __global__ __launch_bounds__(256, 2) void tdnn_kernel(const TdnnArgs a) {
 template <bool GUARD, bool POOL, bool STORE, bool INBF, bool OUTBF, bool X3 = false>
 static hipError_t launch_variant(const TdnnArgs& a, hipStream_t s) {
     auto kern = tdnn_kernel<GUARD, POOL, STORE, INBF, OUTBF, X3>;
-    static bool attr_set = false;   // per-variant; benign if raced (idempotent)
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static LdsOptIn opt;            // per variant and device
+    if (hipError_t e = opt.ensure(reinterpret_cast<const void*>(kern), kLdsBytes); e != hipSuccess) return e;
     const int grid = a.blocks_per_col * a.n_tiles;
     kern<<<dim3(grid), dim3(256), kLdsBytes, s>>>(a);
     return hipGetLastError();

@@ -38,6 +38,25 @@ const int kCtxLen[XVEC_NUM_TDNN] = {5, 3, 3, 1, 1};
 const int kCtxDil[XVEC_NUM_TDNN] = {1, 2, 3, 0, 0};
 
 enum { T_L1 = 0, T_POOL = 5, T_SEG6 = 6, T_SEG7 = 7, T_OUT = 8, T_PACK = 9, T_COUNT = 10 };
+constexpr int kMaxUtts = 65535;   // utterances per call (16-bit utterance counters in the kernels' row maps)
+
+// RAII: the calling thread's current device is whatever it was before the call
+struct DeviceGuard {
+    int prev = -1;
+    bool changed = false;
+    hipError_t enter(int dev) {
+        hipError_t e = hipGetDevice(&prev);
+        if (e != hipSuccess) return e;
+        if (prev != dev) {
+            e = hipSetDevice(dev);
+            changed = e == hipSuccess;
+        }
+        return e;
+    }
+    ~DeviceGuard() {
+        if (changed) (void)hipSetDevice(prev);
+    }
+};
 
 }  // namespace
 
@@ -56,10 +75,12 @@ struct xvec_handle {
     int affN[3], affK[3];
     bool aff_loaded[3];
     // ragged batches: host offsets staged through pinned memory
-    int64_t* offs_pinned;
-    size_t offs_cap;
-    hipEvent_t offs_evt;
-    bool offs_pending;
+    // (allocated once in xvec_create: two slots of kMaxUtts+1 entries, so the ragged entry points
+    // never allocate and block only when a third ragged call arrives before the first one's copy left)
+    int64_t* offs_pinned[2];
+    hipEvent_t offs_evt[2];
+    bool offs_pending[2];
+    int offs_next;
     int num_cu;
     int blocks_per_cu;                 // persistent TDNN blocks per CU (LDS allows 2)
     // profiling
@@ -89,7 +110,7 @@ Plan make_plan(const xvec_handle* h, int64_t total, int B) {
     p.x16 = o;    o += align_up((size_t)p.rows_alloc * h->cin_pad * 2 * 2);   // bf16 rows; bf16x3: hi and lo planes
     p.actA = o;   o += align_up((size_t)p.rows_alloc * nh * 4);
     p.actB = o;   o += align_up((size_t)p.rows_alloc * nh * 4);
-    p.act5 = o;   o += align_up((size_t)p.rows_alloc * n5 * 4);
+    p.act5 = o;   o += align_up((size_t)p.rows_alloc * (n5 > nh ? n5 : nh) * 4);   // also the fp32 output of xvec_tdnn_layer
     p.part_slots = p.m_pad / 32 + B + 1;
     p.part = o;   o += align_up((size_t)p.part_slots * 2 * n5 * 4);
     p.pooled = o; o += align_up((size_t)B * 2 * XVEC_POOL_CHANNELS * 4);
@@ -192,6 +213,15 @@ int run_tdnn(xvec_handle* h, int layer, TdnnVariant v, const void* X, int ldx, i
     a.out_map = out_map;
     a.span = h->geo[layer].ctx_span;
     a.terms = 1;
+    {
+        // the kernel addresses its input with 32-bit byte offsets from a per-tile descriptor: the
+        // largest is (rows of a tile + look-ahead + u*span re-basing) * row bytes (+ the lo plane)
+        const int64_t es = in16 ? 2 : 4;
+        const int64_t reach = ((int64_t)out_map.n_utts * a.span + kRowPadTail) * ldx * es + (x3 ? x_plane : 0);
+        if (reach > 0x7fffffff)
+            return fail(XVEC_ERR_ARG, "layer %d: %d utterances x %d channels exceed 32-bit row offsets; split the batch",
+                        layer, out_map.n_utts, ldx);
+    }
     if (x3) {
         if (x_plane > 0x3fffffff || y_plane > 0x3fffffff)
             return fail(XVEC_ERR_ARG, "batch too large for bf16x3 (plane offsets must fit 30 bits); split it");
@@ -310,32 +340,28 @@ int forward_rows(xvec_handle* h, const float* x_rows, int ldx, const int64_t* of
     return XVEC_OK;
 }
 
-// host offsets -> device (stream ordered, via the handle's pinned staging buffer)
+// host offsets -> device (stream ordered, via the handle's ring of two pinned staging slots).
+// Synchronous part: only when both slots still hold copies that have not left them (a third ragged
+// call enqueued before the first one's copy ran) does this wait for the older one.
 int stage_offsets(xvec_handle* h, const int64_t* offs_host, int B, int64_t* dev, hipStream_t s) {
     const size_t n = (size_t)B + 1;
-    if (h->offs_pending) {               // previous batch's copy must have left the pinned buffer
-        HIP_TRY(hipEventSynchronize(h->offs_evt));
-        h->offs_pending = false;
+    const int slot = h->offs_next;
+    h->offs_next ^= 1;
+    if (h->offs_pending[slot]) {
+        HIP_TRY(hipEventSynchronize(h->offs_evt[slot]));
+        h->offs_pending[slot] = false;
     }
-    if (n > h->offs_cap) {
-        if (h->offs_pinned) HIP_TRY(hipHostFree(h->offs_pinned));
-        h->offs_pinned = nullptr;
-        h->offs_cap = 0;
-        size_t cap = n < 4096 ? 4096 : n * 2;
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->offs_pinned), cap * 8, hipHostMallocDefault));
-        h->offs_cap = cap;
-    }
-    memcpy(h->offs_pinned, offs_host, n * 8);
-    HIP_TRY(hipMemcpyAsync(dev, h->offs_pinned, n * 8, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipEventRecord(h->offs_evt, s));
-    h->offs_pending = true;
+    memcpy(h->offs_pinned[slot], offs_host, n * 8);
+    HIP_TRY(hipMemcpyAsync(dev, h->offs_pinned[slot], n * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipEventRecord(h->offs_evt[slot], s));
+    h->offs_pending[slot] = true;
     return XVEC_OK;
 }
 
 int common_checks(xvec_handle* h, const void* x, int B, int mode, int dtype, const void* out, const void* ws) {
     if (!h) return fail(XVEC_ERR_ARG, "null handle");
     if (!x || !out || !ws) return fail(XVEC_ERR_ARG, "null tensor pointer");
-    if (B < 1 || B > 65535) return fail(XVEC_ERR_ARG, "B must be in [1, 65535] (got %d); split larger batches", B);
+    if (B < 1 || B > kMaxUtts) return fail(XVEC_ERR_ARG, "B must be in [1, %d] (got %d); split larger batches", kMaxUtts, B);
     if (mode != XVEC_MODE_LOGITS && mode != XVEC_MODE_XVEC6 && mode != XVEC_MODE_XVEC7)
         return fail(XVEC_ERR_ARG, "unknown mode %d", mode);
     if (dtype != XVEC_F32 && dtype != XVEC_BF16 && dtype != XVEC_BF16X3) return fail(XVEC_ERR_ARG, "unknown dtype %d", dtype);
@@ -355,7 +381,10 @@ int xvec_create(const xvec_cfg* cfg, xvec_handle** out) {
     if (!cfg || !out) return fail(XVEC_ERR_ARG, "null argument");
     if (cfg->input_size < 1 || cfg->hidden_size < 1 || cfg->num_classes < 1 || cfg->x_vector_size < 1)
         return fail(XVEC_ERR_ARG, "sizes must be positive");
-    HIP_TRY(hipSetDevice(cfg->device));
+    if (cfg->hidden_size > 8192 || cfg->input_size > 8192)
+        return fail(XVEC_ERR_ARG, "input_size / hidden_size above 8192 are not supported (32-bit row offsets)");
+    DeviceGuard guard;                 // allocate on cfg->device, leave the caller's current device as it was
+    HIP_TRY(guard.enter(cfg->device));
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, cfg->device));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
@@ -395,12 +424,16 @@ int xvec_create(const xvec_cfg* cfg, xvec_handle** out) {
             return fail(XVEC_ERR_HIP, "hipMalloc of affine weights failed");
         }
     }
-    bool ok = hipEventCreateWithFlags(&h->offs_evt, hipEventDisableTiming) == hipSuccess;
+    bool ok = true;
+    for (int i = 0; i < 2 && ok; ++i)
+        ok = hipEventCreateWithFlags(&h->offs_evt[i], hipEventDisableTiming) == hipSuccess &&
+             hipHostMalloc(reinterpret_cast<void**>(&h->offs_pinned[i]), (size_t)(kMaxUtts + 1) * 8,
+                           hipHostMallocDefault) == hipSuccess;
     for (int i = 0; i < T_COUNT && ok; ++i)
         ok = hipEventCreate(&h->ev0[i]) == hipSuccess && hipEventCreate(&h->ev1[i]) == hipSuccess;
     if (!ok) {
         xvec_destroy(h);
-        return fail(XVEC_ERR_HIP, "hipEventCreate failed");
+        return fail(XVEC_ERR_HIP, "hipEventCreate / hipHostMalloc failed");
     }
     *out = h;
     return XVEC_OK;
@@ -418,8 +451,10 @@ void xvec_destroy(xvec_handle* h) {
         if (h->affW[i]) (void)hipFree(h->affW[i]);
         if (h->affB[i]) (void)hipFree(h->affB[i]);
     }
-    if (h->offs_pinned) (void)hipHostFree(h->offs_pinned);
-    if (h->offs_evt) (void)hipEventDestroy(h->offs_evt);
+    for (int i = 0; i < 2; ++i) {
+        if (h->offs_pinned[i]) (void)hipHostFree(h->offs_pinned[i]);
+        if (h->offs_evt[i]) (void)hipEventDestroy(h->offs_evt[i]);
+    }
     for (int i = 0; i < T_COUNT; ++i) {
         if (h->ev0[i]) (void)hipEventDestroy(h->ev0[i]);
         if (h->ev1[i]) (void)hipEventDestroy(h->ev1[i]);
@@ -431,6 +466,8 @@ int xvec_load_tdnn(xvec_handle* h, int layer, const float* weight, const float* 
                    const float* bn_bias, const float* bn_mean, const float* bn_var, float eps, xvec_stream stream) {
     if (!h || layer < 0 || layer >= XVEC_NUM_TDNN) return fail(XVEC_ERR_ARG, "bad handle or layer %d", layer);
     if (!weight || !bias) return fail(XVEC_ERR_ARG, "null weight/bias");
+    DeviceGuard guard;                 // launches go to the handle's device whatever the caller's current one is
+    HIP_TRY(guard.enter(h->cfg.device));
     const bool has_bn = bn_weight && bn_bias && bn_mean && bn_var;
     const bool none_bn = !bn_weight && !bn_bias && !bn_mean && !bn_var;
     if (h->cfg.batch_norm ? !has_bn : !none_bn)
@@ -454,6 +491,8 @@ int xvec_load_affine(xvec_handle* h, int which, const float* weight, const float
     const int i = aff_index(which);
     if (!h || i < 0) return fail(XVEC_ERR_ARG, "bad handle or affine id %d", which);
     if (!weight || !bias) return fail(XVEC_ERR_ARG, "null weight/bias");
+    DeviceGuard guard;                 // launches go to the handle's device whatever the caller's current one is
+    HIP_TRY(guard.enter(h->cfg.device));
     hipStream_t s = static_cast<hipStream_t>(stream);
     HIP_TRY(hipMemcpyAsync(h->affW[i], weight, (size_t)h->affN[i] * h->affK[i] * 4, hipMemcpyDeviceToDevice, s));
     HIP_TRY(hipMemcpyAsync(h->affB[i], bias, (size_t)h->affN[i] * 4, hipMemcpyDeviceToDevice, s));
@@ -470,6 +509,8 @@ int xvec_forward(xvec_handle* h, const float* x, const int32_t* lengths_host, in
                  int dtype, float* out, void* workspace, size_t workspace_bytes, xvec_stream stream) {
     int rc = common_checks(h, x, B, mode, dtype, out, workspace);
     if (rc) return rc;
+    DeviceGuard guard;                 // launches go to the handle's device whatever the caller's current one is
+    HIP_TRY(guard.enter(h->cfg.device));
     if (T <= XVEC_TOTAL_CONTEXT)
         return fail(XVEC_ERR_ARG, "T=%d: need at least %d frames (receptive field of the TDNN stack)", T,
                     XVEC_TOTAL_CONTEXT + 1);
@@ -525,6 +566,8 @@ int xvec_forward_packed(xvec_handle* h, const float* x_packed, const int64_t* of
                         int dtype, float* out, void* workspace, size_t workspace_bytes, xvec_stream stream) {
     int rc = common_checks(h, x_packed, B, mode, dtype, out, workspace);
     if (rc) return rc;
+    DeviceGuard guard;                 // launches go to the handle's device whatever the caller's current one is
+    HIP_TRY(guard.enter(h->cfg.device));
     if (!offsets_host) return fail(XVEC_ERR_ARG, "null offsets");
     if (offsets_host[0] != 0) return fail(XVEC_ERR_ARG, "offsets[0] must be 0");
     for (int i = 0; i < B; ++i) {
@@ -559,6 +602,8 @@ int xvec_tdnn_layer(xvec_handle* h, int layer, const float* x, int32_t B, int32_
     if (!x || !y || !workspace) return fail(XVEC_ERR_ARG, "null tensor pointer");
     if (dtype != XVEC_F32 && dtype != XVEC_BF16 && dtype != XVEC_BF16X3) return fail(XVEC_ERR_ARG, "unknown dtype %d", dtype);
     if (!h->tdnn_loaded[layer]) return fail(XVEC_ERR_STATE, "time_context_layers.%d weights not loaded", layer);
+    DeviceGuard guard;                 // launches go to the handle's device whatever the caller's current one is
+    HIP_TRY(guard.enter(h->cfg.device));
     const TdnnGeom& g = h->geo[layer];
     if (B < 1 || T <= g.ctx_span) return fail(XVEC_ERR_ARG, "need B>=1 and T>%d (got B=%d T=%d)", g.ctx_span, B, T);
     const Plan p = make_plan(h, (int64_t)B * T, B);
@@ -620,6 +665,8 @@ int xvec_affine(xvec_handle* h, int which, const float* x, int32_t M, int relu, 
     if (!h || i < 0) return fail(XVEC_ERR_ARG, "bad handle or affine id %d", which);
     if (!x || !y || M < 1) return fail(XVEC_ERR_ARG, "bad x/y/M");
     if (!h->aff_loaded[i]) return fail(XVEC_ERR_STATE, "affine %d weights not loaded", which);
+    DeviceGuard guard;                 // launches go to the handle's device whatever the caller's current one is
+    HIP_TRY(guard.enter(h->cfg.device));
     HIP_TRY(launch_affine_f32(x, h->affW[i], h->affB[i], y, M, h->affN[i], h->affK[i], relu,
                               static_cast<hipStream_t>(stream)));
     return XVEC_OK;

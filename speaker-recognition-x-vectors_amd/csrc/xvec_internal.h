@@ -42,6 +42,23 @@ __device__ __forceinline__ int utt_of_row(const RowMap& m, int64_t p) {
 }
 #endif
 
+// Opt-in to more than 64 KiB of dynamic LDS, once per (kernel, device): the attribute belongs to the
+// device that is current when it is set, so one flag per process would leave a second device without it.
+struct LdsOptIn {
+    bool done[64] = {};
+    hipError_t ensure(const void* fn, int bytes) {
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        if (dev < 0 || dev >= 64 || !done[dev]) {
+            e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            if (e != hipSuccess) return e;
+            if (dev >= 0 && dev < 64) done[dev] = true;   // benign if raced (idempotent)
+        }
+        return hipSuccess;
+    }
+};
+
 // One frame-level layer as an implicit GEMM over the flat frame axis:
 //   Y[p, n] = bn( relu( sum_{tap,c} X[p + u(p)*span + tap*tap_rows, c] * W[n, tap, c] + bias[n] ) )
 // for every compact output row p; u(p)*span re-bases the row into the (longer) input layout.

@@ -42,15 +42,22 @@ def balanced_order(lengths: Sequence[int], world: int) -> List[List[int]]:
 
 
 def gather_embeddings(local: torch.Tensor, n_total: int, group=None,
-                      order: Sequence[Sequence[int]] = None) -> torch.Tensor:
+                      order: Sequence[Sequence[int]] = None, force: bool = False) -> torch.Tensor:
     """All-gather the per-rank [n_local, D] embeddings into [n_total, D] on every rank.
 
     One all_gather_into_tensor of equal-size (padded) shards; rows are then trimmed back
-    (contiguous-block sharding) or scattered to their original positions (`order`)."""
+    (contiguous-block sharding) or scattered to their original positions (`order`).
+    A single rank needs no exchange and returns `local` (re-ordered when `order` is given);
+    `force=True` runs the collective and the assembly even then (one-GPU rehearsal of the
+    multi-GPU code path; needs an initialised process group)."""
     import torch.distributed as dist
     world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if world == 1:
-        return local
+    if world == 1 and not force:
+        if order is None:
+            return local
+        out = torch.empty((n_total, local.shape[1]), dtype=local.dtype, device=local.device)
+        out[torch.as_tensor(list(order[0]), dtype=torch.long, device=local.device)] = local
+        return out
     D = local.shape[1]
     if order is None:
         counts = [shard_bounds(n_total, r, world)[1] - shard_bounds(n_total, r, world)[0] for r in range(world)]
@@ -62,7 +69,10 @@ def gather_embeddings(local: torch.Tensor, n_total: int, group=None,
         send = torch.zeros((per, D), dtype=local.dtype, device=local.device)
         send[: local.shape[0]] = local
     recv = torch.empty((world * per, D), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(recv, send.contiguous(), group=group)
+    if dist.is_initialized():
+        dist.all_gather_into_tensor(recv, send.contiguous(), group=group)
+    else:                                   # force=True without a process group: world is 1
+        recv.copy_(send)
     if order is None:
         if all(c == per for c in counts):
             return recv
@@ -76,7 +86,7 @@ def gather_embeddings(local: torch.Tensor, n_total: int, group=None,
 
 
 def extract_sharded(extract_fn: Callable[[torch.Tensor], torch.Tensor], make_batch: Callable[[int, int], torch.Tensor],
-                    n_total: int, batch_size: int = 256, group=None) -> torch.Tensor:
+                    n_total: int, batch_size: int = 256, group=None, force_collective: bool = False) -> torch.Tensor:
     """Utterance-sharded extraction job (BASELINE config 4).
 
     make_batch(lo, hi) returns the device tensor [hi-lo, T, C] for global utterances
@@ -95,7 +105,22 @@ def extract_sharded(extract_fn: Callable[[torch.Tensor], torch.Tensor], make_bat
     else:   # rank without work still has to join the collective: learn D from a peer-sized dummy
         probe = extract_fn(make_batch(0, 1))
         local = probe[:0]
-    return gather_embeddings(local, n_total, group)
+    return gather_embeddings(local, n_total, group, force=force_collective)
+
+
+def extract_balanced(extract_ragged: Callable[[List[int]], torch.Tensor], lengths: Sequence[int], group=None,
+                     force_collective: bool = False) -> torch.Tensor:
+    """Variable-length job (BASELINE config 3 sharded): utterances are dealt to the ranks by total
+    frames (`balanced_order`), every rank extracts its own list with
+    `extract_ragged(indices) -> [len(indices), D]` (e.g. a padded batch + `lengths=` call of
+    model.extract_x_vec), and one all-gather + un-permute returns [len(lengths), D] in input
+    order on every rank."""
+    import torch.distributed as dist
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    order = balanced_order(lengths, world)
+    local = extract_ragged(order[rank])
+    return gather_embeddings(local, len(lengths), group, order=order, force=force_collective)
 
 
 # --------------------------------------------------------------------------- records / CSV

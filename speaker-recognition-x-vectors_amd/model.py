@@ -60,6 +60,12 @@ class _Engine:
         self.workspace: Optional[torch.Tensor] = None
         self.signature = None
 
+    def workspace_bytes(self, total_frames: int, n_utts: int) -> int:
+        need = _hip.lib.xvec_workspace_bytes(self.h, total_frames, n_utts)
+        if need == 0:
+            raise _hip.XvecError(_hip.ERR_ARG, "xvec_workspace_bytes returned 0")
+        return int(need)
+
     def __del__(self):
         h, self.h = getattr(self, "h", None), None
         if h:
@@ -69,9 +75,7 @@ class _Engine:
                 pass
 
     def ensure_workspace(self, total_frames: int, n_utts: int):
-        need = _hip.lib.xvec_workspace_bytes(self.h, total_frames, n_utts)
-        if need == 0:
-            raise _hip.XvecError(_hip.ERR_ARG, "xvec_workspace_bytes returned 0")
+        need = self.workspace_bytes(total_frames, n_utts)
         if self.workspace is None or self.workspace.numel() < need:
             self.workspace = None          # release before growing
             self.workspace = torch.empty(int(need * 1.25) if total_frames > 4096 else need, dtype=torch.uint8,
@@ -194,11 +198,14 @@ class XVectorModel(nn.Module):
                 "its checkpoint here.")
 
     def _engine(self, device: torch.device) -> _Engine:
+        if device.index is None:
+            device = torch.device(device.type, torch.cuda.current_device())
         key = (device.type, device.index)
-        eng = self._engines.get(key)
-        if eng is None:
-            eng = self._engines[key] = _Engine(self.hparams, device)
-        self._sync_weights(eng)
+        with torch.cuda.device(device):     # handle creation and the packing kernels run on `device`
+            eng = self._engines.get(key)
+            if eng is None:
+                eng = self._engines[key] = _Engine(self.hparams, device)
+            self._sync_weights(eng)
         return eng
 
     def _hot_tensors(self):
@@ -271,7 +278,7 @@ class XVectorModel(nn.Module):
         arr = (C.c_int32 * B)(*lengths)
         return arr, lengths
 
-    def _run(self, x: torch.Tensor, mode: int, lengths=None) -> torch.Tensor:
+    def _run(self, x: torch.Tensor, mode: int, lengths=None, workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
         x = self._prep_input(x, "XVectorModel")
         B, T, Cin = x.shape
         if Cin != self.hparams["input_size"]:
@@ -284,7 +291,10 @@ class XVectorModel(nn.Module):
             raise ValueError(f"lengths must lie in [15, T={T}]")
         eng = self._engine(x.device)
         total = sum(lens) if lens is not None else B * T
-        ws, ws_bytes = eng.ensure_workspace(total, B)
+        if workspace is not None:           # caller-owned scratch (GraphedPath: its pointers are baked into a graph)
+            ws, ws_bytes = workspace.data_ptr(), workspace.numel()
+        else:
+            ws, ws_bytes = eng.ensure_workspace(total, B)
         n_out = self.hparams["num_classes"] if mode == _hip.MODE_LOGITS else self.hparams["x_vector_size"]
         out = torch.empty((B, n_out), dtype=torch.float32, device=x.device)
         with torch.cuda.device(x.device):
@@ -413,13 +423,18 @@ class GraphedPath:
     def __init__(self, model: XVectorModel, example: torch.Tensor, logits: bool = False):
         _require_gpu(example, "graphed")
         self._x = example.detach().float().contiguous().clone()
-        fn = model.forward if logits else model.extract_x_vec
-        fn(self._x)                                    # weights packed, workspace sized, outside the capture
+        mode = _hip.MODE_LOGITS if logits else (_hip.MODE_XVEC7 if model.x_vec_extract_layer == 7 else _hip.MODE_XVEC6)
+        eng = model._engine(self._x.device)            # weights packed outside the capture
+        B, T, _ = self._x.shape
+        # The graph bakes raw pointers into the scratch buffer, so the graph OWNS its scratch: the
+        # engine's shared workspace is reallocated whenever a later, larger batch needs more room.
+        self._ws = torch.empty(eng.workspace_bytes(B * T, B), dtype=torch.uint8, device=self._x.device)
+        model._run(self._x, mode, workspace=self._ws)
         torch.cuda.synchronize(self._x.device)
         self._graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._graph):
-            self._y = fn(self._x)
-        self._model = model                            # keeps the engine (workspace, weights) alive
+            self._y = model._run(self._x, mode, workspace=self._ws)
+        self._model = model                            # keeps the engine (packed weights) alive
 
     def __call__(self, x: torch.Tensor) -> torch.Tensor:
         if x.shape != self._x.shape:

@@ -21,7 +21,9 @@ Fixture groups:
   g4_full.npz          extract_x_vec (layer 6, 7) and forward logits, B in {1,8}, T in {299,300}
   g5_ragged.npz        lengths {200,333,1000} each run at batch=1 un-padded
   g6_tiny.npz          reduced-width model with its weights stored in full (+ no-BN variant)
-  g7_caller.npz        test_step/test_epoch_end I/O: row order + fp32->float64 widening
+  g7_caller.npz        test_step/test_epoch_end I/O: row order + fp32->float64 widening; the CSV text
+                       pandas writes from the reference's record list and what the reference's reader
+                       parses back from it
 """
 import importlib
 import os
@@ -220,6 +222,18 @@ def main_():
               "out_labels": np.array([r[1] for r in main.x_vector], dtype=np.int64),
               "out_vecs": np.stack([r[2] for r in main.x_vector])}
         assert g7["out_vecs"].dtype == np.float64
+        # the file the reference writes from that list (main.py:246-247: pd.DataFrame(x_vector).to_csv(path))
+        # -- pandas output, i.e. data -- and what the reference's own reader makes of it
+        # (plda_score_stat.py:13-17, the same three lines as main.py:276-279)
+        import io
+        csv_text = main.pd.DataFrame(main.x_vector).to_csv()
+        g7["csv_text"] = np.array(csv_text)
+        pss = importlib.import_module("plda_score_stat")
+        # (speechbrain's StatObject_SB arrives by `import *` from the absent package: same stand-in as above)
+        importlib.import_module("plda_classifier").StatObject_SB = _Anything
+        rd = pss.plda_score_stat_object(main.pd.read_csv(io.StringIO(csv_text)))
+        g7["read_ids"] = np.array([str(v) for v in rd.x_id_test])
+        g7["read_vecs"] = np.asarray(rd.x_vec_test, dtype=np.float64)
         save("g7_caller.npz", **g7)
 
 

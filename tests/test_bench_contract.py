@@ -33,3 +33,14 @@ def test_bench_line(extra):
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "embeddings/s" and c["sample"]
+    # SURVEY 8(d) protocol: B=1 and B=64, all usable cores and one thread
+    assert set(c["legs"]) == {"b64_all", "b1_all", "b64_1t", "b1_1t"}
+    assert c["legs"]["b64_1t"]["threads"] == 1 and c["legs"]["b1_all"]["batch"] == 1
+    assert c["value"] == c["legs"]["b64_all"]["embeddings_per_s"] and c["cores"] == c["legs"]["b64_all"]["threads"]
+    cfg = d["config"]
+    if not extra:      # the default line carries the other single-GPU configs as secondary fields (never `value`)
+        for key in ("bf16_embeddings_per_s", "bf16_roofline_frac", "ragged_utt_per_s", "ragged_valid_frames_per_s"):
+            assert isinstance(cfg[key], float) and cfg[key] > 0, key
+        assert cfg["bf16_embeddings_per_s"] > d["value"]          # bf16 matrix rate is 16x the fp32 one
+    else:
+        assert "bf16_embeddings_per_s" not in cfg

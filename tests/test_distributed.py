@@ -34,11 +34,8 @@ def _worker(rank, world, port, n_total, ragged, out_dir):
         got = extract.extract_sharded(_fake_extract, _make_batch, n_total, batch_size=4)
     else:
         lengths = [5 + (i * 7) % 16 for i in range(n_total)]
-        order = extract.balanced_order(lengths, world)
-        mine = order[rank]
         x = _make_batch(0, n_total)
-        local = _fake_extract(x[mine]) if mine else torch.zeros((0, 8))
-        got = extract.gather_embeddings(local, n_total, order=order)
+        got = extract.extract_balanced(lambda mine: _fake_extract(x[mine]) if mine else torch.zeros((0, 8)), lengths)
     torch.save(got, os.path.join(out_dir, f"r{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
@@ -60,3 +57,38 @@ def test_single_process_is_identity():
     from xvector_amd import extract
     got = extract.extract_sharded(_fake_extract, _make_batch, 10, batch_size=3)
     assert torch.equal(got, _fake_extract(_make_batch(0, 10)))
+
+
+def _worker_world1(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    from xvector_amd import extract
+    a = extract.extract_sharded(_fake_extract, _make_batch, 10, batch_size=3, force_collective=True)
+    lengths = [5 + (i * 7) % 16 for i in range(10)]
+    x = _make_batch(0, 10)
+    b = extract.extract_balanced(lambda mine: _fake_extract(x[mine]), lengths, force_collective=True)
+    torch.save((a, b), os.path.join(out_dir, "w1.pt"))
+    dist.destroy_process_group()
+
+
+def test_forced_collective_at_world1(tmp_path):
+    """The one-GPU rehearsal path of the RCCL leg (tests/test_multigpu_gpu.py) on gloo: with
+    force_collective the all-gather and the assembly run even for a single rank."""
+    mp.spawn(_worker_world1, args=(1, 31500 + os.getpid() % 2000, str(tmp_path)), nprocs=1, join=True)
+    a, b = torch.load(os.path.join(str(tmp_path), "w1.pt"))
+    want = _fake_extract(_make_batch(0, 10))
+    assert torch.equal(a, want) and torch.equal(b, want)
+
+
+def test_single_rank_order_is_undone():
+    """gather_embeddings(order=...) without a process group: rows return to input order."""
+    sys.path.insert(0, ROOT)
+    from xvector_amd import extract
+    x = _make_batch(0, 9)
+    perm = [4, 0, 8, 2, 6, 1, 7, 3, 5]
+    got = extract.gather_embeddings(_fake_extract(x[perm]), 9, order=[perm])
+    assert torch.equal(got, _fake_extract(x))
+    got = extract.gather_embeddings(_fake_extract(x[perm]), 9, order=[perm], force=True)
+    assert torch.equal(got, _fake_extract(x))

@@ -166,3 +166,82 @@ def test_lightning_checkpoint_ingestion(tmp_path, synth):
     assert m.x_vec_extract_layer == 7 and m.hparams["hidden_size"] == 32
     for k, v in sd.items():
         assert torch.equal(m.state_dict()[k], v), k
+
+
+def test_csv_writer_matches_reference_file_byte_for_byte(tmp_path):
+    """N1 pinned to the reference's own writer: g7_caller.npz holds the text pandas produced from the
+    record list the reference accumulated (main.py:142-146, 246-247) and what the reference's reader
+    (plda_score_stat.py:16-17 = main.py:276-279) parsed back.  Our writer must emit the same bytes from
+    the same records, our reader the same arrays from that text."""
+    from xvector_amd import extract
+    g = load_golden("g7_caller.npz")
+    recs = [(str(i), int(l), np.asarray(v, dtype=np.float64))
+            for i, l, v in zip(g["out_ids"], g["out_labels"], g["out_vecs"])]
+    path = str(tmp_path / "x_vector_test.csv")
+    extract.write_x_vector_csv(recs, path, npy_sidecar=False)
+    assert open(path, newline="").read() == str(g["csv_text"])
+    ref_path = str(tmp_path / "ref.csv")
+    with open(ref_path, "w", newline="") as f:
+        f.write(str(g["csv_text"]))
+    ids, labels, vecs = extract.read_x_vector_csv(ref_path)
+    assert ids.tolist() == g["read_ids"].tolist() and labels.tolist() == g["out_labels"].tolist()
+    assert np.array_equal(vecs, g["read_vecs"])
+    # to_records on the fp32 vectors gives the reference's records (exact widening), hence the same file
+    recs2 = extract.to_records(torch.from_numpy(g["out_vecs"].astype(np.float32)), torch.from_numpy(g["labels"]),
+                               g["ids"].tolist())
+    extract.write_x_vector_csv(recs2, path, npy_sidecar=False)
+    assert open(path, newline="").read() == str(g["csv_text"])
+
+
+def test_checkpoint_with_unimportable_lightning_classes(tmp_path, synth):
+    """N2: a real Lightning 1.6 checkpoint pickles `hyper_parameters` as
+    pytorch_lightning.utilities.parsing.AttributeDict (a dict subclass) and callback state keyed by
+    classes of pytorch_lightning.callbacks; none of them is importable here (main.py:56,198,213).
+    Build such a pickle from a temporary module of that name, remove the module, load."""
+    import sys
+    import types
+    import xvector_amd as xa
+    names = ["pytorch_lightning", "pytorch_lightning.utilities", "pytorch_lightning.utilities.parsing",
+             "pytorch_lightning.callbacks", "pytorch_lightning.callbacks.model_checkpoint"]
+    assert not any(n in sys.modules for n in names), "test needs Lightning to be absent"
+    mods = {n: types.ModuleType(n) for n in names}
+
+    class AttributeDict(dict):                      # Lightning's: a dict with attribute access
+        def __getattr__(self, key):
+            try:
+                return self[key]
+            except KeyError as exc:
+                raise AttributeError(key) from exc
+    AttributeDict.__module__, AttributeDict.__qualname__ = names[2], "AttributeDict"
+    mods[names[2]].AttributeDict = AttributeDict
+
+    class ModelCheckpoint:                          # object state restored through __setstate__/__dict__
+        def __init__(self):
+            self.best_model_score = torch.tensor(0.5)
+            self.monitor = "val_step_loss"
+    ModelCheckpoint.__module__, ModelCheckpoint.__qualname__ = names[4], "ModelCheckpoint"
+    mods[names[4]].ModelCheckpoint = ModelCheckpoint
+
+    hp = AttributeDict(input_size=24, hidden_size=32, num_classes=10, x_vector_size=16, x_vec_extract_layer=7,
+                       batch_size=512, learning_rate=0.001, batch_norm=True, dropout_p=0.0,
+                       augmentations_per_sample=2, data_folder_path="data")
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in synth.make_state_dict(
+        seed=3, hidden_size=32, num_classes=10, x_vector_size=16).items()}
+    ckpt = {"epoch": 3, "global_step": 100, "pytorch-lightning_version": "1.6.4", "state_dict": dict(sd),
+            "hyper_parameters": hp, "optimizer_states": [{}], "callbacks": {"ModelCheckpoint": ModelCheckpoint()},
+            "hparams_name": "kwargs"}
+    path = str(tmp_path / "epoch=3.ckpt")
+    sys.modules.update(mods)
+    try:
+        torch.save(ckpt, path)
+    finally:
+        for n in names:
+            sys.modules.pop(n, None)
+    with pytest.raises(Exception):                  # the stock loader cannot resolve the classes ...
+        torch.load(path, map_location="cpu", weights_only=False)
+    m = xa.XVectorModel.load_from_checkpoint(path)  # ... the lenient one reads them as plain dicts
+    assert m.x_vec_extract_layer == 7 and m.hparams["hidden_size"] == 32 and m.hparams["num_classes"] == 10
+    for k, v in sd.items():
+        assert torch.equal(m.state_dict()[k], v), k
+    # overrides win over stored hyper-parameters (Lightning's load_from_checkpoint(**kwargs))
+    assert xa.XVectorModel.load_from_checkpoint(path, x_vec_extract_layer=6).x_vec_extract_layer == 6

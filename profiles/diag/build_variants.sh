@@ -1,0 +1,24 @@
+#!/bin/bash
+# Diagnostic builds of the library next to the shipping one (not product; profiles/diag/bin is git-ignored):
+#   libxvec_hip_diag.so     -DXVEC_DIAG      in-kernel s_memtime stamps (tdnn_layer.hip, tdnn_pp.hip)
+#   libxvec_hip_knock<m>.so -DXVEC_KNOCK=<m> timing-only knock-outs of tdnn_pp.hip (bit 0 DMA, 1 LDS reads, 2 epilogue)
+set -e
+cd "$(dirname "$0")/../../speaker-recognition-x-vectors_amd/csrc"
+out=../../profiles/diag/bin
+FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -Wno-pass-failed -Wno-inline-asm"
+mkdir -p $out /tmp/xv_base /tmp/xv_diag
+for f in tdnn_layer pool affine pack mfcc score xvec_api; do
+  /opt/rocm/bin/hipcc $FLAGS -c $f.hip -o /tmp/xv_base/$f.o &
+done
+/opt/rocm/bin/hipcc $FLAGS -DXVEC_DIAG -c tdnn_layer.hip -o /tmp/xv_diag/tdnn_layer.o &
+/opt/rocm/bin/hipcc $FLAGS -DXVEC_DIAG -c tdnn_pp.hip -o /tmp/xv_diag/tdnn_pp.o &
+for m in ${KNOCKS:-0 1 2 3 4 7}; do
+  /opt/rocm/bin/hipcc $FLAGS -DXVEC_KNOCK=$m -c tdnn_pp.hip -o /tmp/xv_base/knock_pp_$m.o &
+done
+wait
+objs=$(ls /tmp/xv_base/*.o | grep -v knock_pp_ | grep -v tdnn_layer.o)
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $out/libxvec_hip_diag.so $objs /tmp/xv_diag/tdnn_layer.o /tmp/xv_diag/tdnn_pp.o
+for m in ${KNOCKS:-0 1 2 3 4 7}; do
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $out/libxvec_hip_knock$m.so $objs /tmp/xv_base/tdnn_layer.o /tmp/xv_base/knock_pp_$m.o
+done
+ls $out

@@ -95,6 +95,13 @@ hipError_t launch_pack_tdnn_bf16(const float* W, const TdnnGeom& geo, void* Wf16
     return hipGetLastError();
 }
 
+// row-major bf16 [n_pad][k_pad] (64-element chunks, taps innermost): both operands of tdnn_pp.hip reach
+// LDS by DMA in 128-byte row slabs, so its weights keep plain rows
+hipError_t launch_pack_tdnn_rows_bf16(const float* W, const TdnnGeom& geo, void* Wr16, hipStream_t s) {
+    pack_tdnn_weight_kernel<__bf16><<<1024, 256, 0, s>>>(W, geo, static_cast<__bf16*>(Wr16));
+    return hipGetLastError();
+}
+
 // x[B,T,C] -> packed rows out[offsets[u] + t][c_pad] for t < len_u (zero padded channels).
 template <typename TO>
 __global__ void pack_rows_kernel(const float* __restrict__ x, const int64_t* __restrict__ offsets, int T,

@@ -114,6 +114,25 @@ __global__ __launch_bounds__(256) void pool_finalize_kernel(const PoolFinalizeAr
     const int ch = blockIdx.x * 256 + threadIdx.x;
     if (ch >= a.C) return;
     const int64_t off = row_off(a.map, u), end = row_off(a.map, u + 1);   // pooled rows are [off, end)
+    if (a.scale != nullptr) {
+        // raw-sum partials of tdnn_pp.hip: (S1, S2) = sums of r and r^2, r = relu(z + bias), per (sub-tile,
+        // utterance); y = scale*r + shift.  Totals and the difference S2 - S1^2/n in fp64.
+        double s1 = 0.0, s2 = 0.0;
+        for (int64_t sub = off / a.sub_rows; sub * a.sub_rows < end; ++sub) {
+            const float* p = a.part + (sub + u) * (int64_t)(2 * a.n_pad);
+            s1 += (double)p[ch];
+            s2 += (double)p[a.n_pad + ch];
+        }
+        const double n = (double)(end - off);
+        const double sc = (double)a.scale[ch], sh = (double)a.shift[ch];
+        const double mean_r = s1 / n;
+        double var_r = (s2 - s1 * mean_r) / (n - 1.0);
+        var_r = var_r > 0.0 ? var_r : 0.0;
+        float* o = a.out + (int64_t)u * 2 * a.C;
+        o[ch] = (float)(sh + sc * mean_r);
+        o[a.C + ch] = (n > 1.0) ? (float)((sc < 0.0 ? -sc : sc) * sqrt(var_r)) : __builtin_nanf("");
+        return;
+    }
     float n = 0.f, mean = 0.f, m2 = 0.f;
     // four sub-tiles per trip, their eight loads issued before the first merge: the kernel is a chain
     // of ~10 dependent round trips per thread otherwise (12 us for 31 MB of partials)

@@ -1,0 +1,773 @@
+// Frame-level TDNN layer, bf16 operands / fp32 accumulation, for the large batches of the bf16 path
+// (BASELINE configs[4]): the same implicit GEMM as tdnn_layer.hip (tdnn_layer.py:26-41 of the
+// reference: context gather -> Linear -> ReLU -> eval BatchNorm, optional fused statistics pooling,
+// main.py:59-63) with a machine mapping built for the bf16 matrix rate.
+//
+// Why a second mapping.  The 128x128-tile kernel of tdnn_layer.hip moves 512 B from L2 per
+// v_mfma_f32_32x32x16_bf16; at the bf16 rate that is ~52 B/clk per CU against the ~64 B/clk the
+// L2 -> CU path delivers, so loads and MFMAs add up instead of overlapping (DESIGN.md 8 [4]).  Here:
+//   * ONE 512-thread block per CU, tile = up to 256 frames x 256 channels, K in 64-wide tiles
+//     (128-byte rows): 256 B per MFMA, half the L2 traffic.
+//   * both operands go global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds: no staging registers,
+//     no ds_write), 1-KiB pieces of 8 rows x 128 B; the 16-byte-chunk XOR swizzle that makes the
+//     ds_read_b128 fragment reads conflict-free is applied on the SOURCE address (the LDS image of
+//     a DMA piece is lane-linear).  Two 64-KiB LDS buffers (K-tile parity), refilled slot by slot
+//     two K-tiles ahead behind COUNTED s_waitcnt vmcnt -- the queue is never drained in the loop.
+//   * 8 waves = 2 groups (frames halves) x 4 (64-channel columns); wave tile = MR x 2 accumulators
+//     of 32x32 (MR = 3 or 4 per tile: 192 or 256 frames).  The two waves of a SIMD belong to
+//     different groups and run one barrier apart ("ping-pong"): while one issues its 16 MFMAs of a
+//     phase, the other reads its next fragments from LDS and issues its DMA pieces, then they swap.
+//     A phase = 2 accumulator rows x 2 columns x 4 k-steps; 2 phases per K-tile.
+//   * persistent: a block owns a contiguous range of 64-frame units of one 256-channel column and
+//     cuts it into tiles of 3 or 4 units, as equal as possible (a partial round of fixed 256-row
+//     tiles would idle a quarter of the chip at B=256: 584 tiles over 256 CUs).
+//   * store epilogue: the accumulators hold CHANNELS in their registers and frames on the lanes
+//     (weights are the MFMA A operand), so a lane owns 4 consecutive channels per register group;
+//     bias + ReLU + folded BatchNorm from per-channel constants kept in LDS, packed to bf16,
+//     v_permlane32_swap pairs the lane halves and every store is 16 bytes.
+//     Pooling epilogue (layer 5): operands swapped (frames in the registers, channel on the lane),
+//     so the per-(32-frame group, utterance) mean / M2 partials are register sums (pool_group).
+// The next tile's first K-tiles are requested before the epilogue, so the DMA flies under it.
+#include "tdnn_common.h"
+
+namespace xvec {
+namespace pp {
+
+constexpr int kRowB = 128;                        // one K-tile slab of one row: 64 bf16
+constexpr int kAccRowB = 32 * kRowB;              // 32 frames: 4 KiB = 4 DMA pieces
+constexpr int kABytes = 2 * 4 * kAccRowB;         // [group][acc row][32 frames]: 32 KiB
+constexpr int kWBytes = 256 * kRowB;              // 256 channels: 32 KiB = 32 DMA pieces
+constexpr int kBufBytes = kABytes + kWBytes;      // 64 KiB
+constexpr int kConstOff = 2 * kBufBytes;
+constexpr int kConstBytes = 3 * 256 * 4;          // bias | scale | shift of the block's 256 channels
+constexpr int kLdsBytes = kConstOff + kConstBytes;
+constexpr int kThreads = 512;
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_ptr;
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ i32x4 make_srd(const void* p) {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    i32x4 d;
+    d.x = (int)__builtin_amdgcn_readfirstlane((unsigned)v);
+    d.y = (int)(__builtin_amdgcn_readfirstlane((unsigned)(v >> 32)) & 0xffffu);   // stride 0
+    d.z = 0x7fffffff;                                                            // num_records (bytes)
+    d.w = 0x00020000;
+    return d;
+}
+
+// One DMA piece: 64 lanes x 16 B from per-lane source offsets to 1 KiB of LDS at `dst` (wave
+// uniform).  Inline asm on purpose: hipcc would wait vmcnt(0) for the builtin form before the
+// next ds_read; this way the pieces are invisible to its bookkeeping and are waited for by hand
+// (counted vmcnt before the barrier that publishes them).
+__device__ __forceinline__ void dma16(const i32x4& rsrc, unsigned dst, int voff, int soff) {
+    // dst / soff / rsrc are SALU results (no VALU-written SGPR feeds the load: no wait states needed
+    // beyond the one after the M0 write); M0 is declared clobbered instead of saved and restored
+    asm volatile(
+        "s_mov_b32 m0, %0\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %1, %2, %3 offen lds"
+        :
+        : "s"(dst), "v"(voff), "s"(rsrc), "s"(soff)
+        : "memory", "m0");
+}
+
+#ifdef XVEC_DIAG
+// Diagnostic build only (make DIAG=1): s_memtime stamps of one wave per group, summed per segment kind.
+// slot = 16 * group + kind; kinds: 0-5 phase 0 (issue, wait, barrier, mfma, barrier, -), 6-11 phase 1
+__device__ unsigned long long g_pp_diag[2 * 512 * 32];   // [pooling variant][block][group][kind]
+#define PP_STAMP(k_)                                                                               \
+    {                                                                                              \
+        SB();                                                                                      \
+        unsigned long long now_;                                                                   \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory");              \
+        dsum[k_] += now_ - dprev;                                                                  \
+        dprev = now_;                                                                              \
+        SB();                                                                                      \
+    }
+#else
+#define PP_STAMP(k_)
+#endif
+#ifdef XVEC_KNOCK
+// Timing-only knock-outs, compile time (-DXVEC_KNOCK=mask; results are garbage):
+//   bit 0: no DMA pieces in the K loop     bit 1: no LDS fragment reads (fragments stay zero)
+//   bit 2: no epilogue (stores / pooling)
+#define PP_KNOCK_DMA ((XVEC_KNOCK & 1) != 0)
+#define PP_KNOCK_RD ((XVEC_KNOCK & 2) != 0)
+#define PP_KNOCK_EPI ((XVEC_KNOCK & 4) != 0)
+#define PP_KNOCK_RDW ((XVEC_KNOCK & 8) != 0)     // bit 3: no W fragment reads only
+#define PP_KNOCK_RDA ((XVEC_KNOCK & 16) != 0)    // bit 4: no A fragment reads only
+#else
+#define PP_KNOCK_RDW false
+#define PP_KNOCK_RDA false
+#define PP_KNOCK_DMA false
+#define PP_KNOCK_RD false
+#define PP_KNOCK_EPI false
+#endif
+// lgkmcnt(0) as the BUILTIN (0xC07F = lgkmcnt 0, vmcnt / expcnt untouched): hipcc's wait-count pass sees it and
+// knows every earlier LDS read is back.  As inline asm it did not, and put lgkmcnt(3..0) waits for
+// fragments read a segment earlier in front of the MFMAs -- behind the freshly issued prefetch reads,
+// which serialised those reads with the MFMAs they were meant to hide under.
+#define PP_WAIT_LGKM()                          \
+    {                                           \
+        SB();                                   \
+        __builtin_amdgcn_s_waitcnt(0xC07F);     \
+        SB();                                   \
+    }
+#define PP_WAIT_VM(n_) asm volatile("s_waitcnt vmcnt(" #n_ ")" ::: "memory")
+#define PP_BARRIER() \
+    {                \
+        SB();        \
+        __builtin_amdgcn_s_barrier(); \
+        SB();        \
+    }
+
+// Tile = `mr` accumulator rows per group (rows m0 .. m0 + 64*mr), of which rows below `valid_end`
+// belong to this block.
+struct Tile {
+    int64_t m0;
+    int64_t valid_end;
+    int mr;
+};
+
+// Row offset of a ragged batch through the SCALAR cache.  hipcc loads `offsets[u]` with a vector load even
+// for a provably uniform u (the pointer is not known to be read-only), and the s_waitcnt vmcnt(0) it puts
+// behind that load would drain this kernel's DMA queue; the array is written by the host before the launch.
+__device__ __forceinline__ int64_t sload_i64(const int64_t* p) {
+    int64_t v;
+    asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+    return v;
+}
+
+struct Stream {
+    i32x4 xrsrc, wrsrc;
+    int av0, av1, av2, av3;     // per-lane source byte offsets of this wave's A piece of acc rows 0..3
+    int wv0;                    // and of its first W piece; the others are 64 channel rows (w64 bytes, scalar) apart
+    int w64;
+    unsigned lds_a, lds_w;      // LDS byte address (buffer 0) of this wave's A piece of acc row 0 / its first W piece
+    int row_in_group;           // this lane's row within its group's acc row 0 (A pieces), and the byte offset of
+    int a_chunk;                // the (swizzled) 16-byte chunk it fetches within a 128-byte K-tile slab
+    int pending_stores;         // stores the previous tile's epilogue issued after this tile's first K-tiles (-1: unknown)
+    int u_tile;                 // utterance holding the stream tile's first row, and where the next one starts
+    int64_t off_next;
+};
+
+// per-lane source offsets of the wave's A pieces for the tile at row t.m0 (see set_tile_rows_impl in
+// tdnn_layer.hip: compact output row p of utterance u reads input rows p + u*span; the utterance
+// boundaries inside the tile are walked with block-uniform values, each lane counts the ones its
+// rows have passed)
+template <bool RAGGED>
+__device__ __forceinline__ void set_rows(const TdnnArgs& a, const Tile& t, int grp, Stream& st) {
+    const int n_last = a.out_map.n_utts - 1;
+    const int64_t t_out = a.out_map.fixed_T - a.out_map.cum;
+    auto next_off = [&](int u) -> int64_t {
+        if (RAGGED) return sload_i64(a.out_map.offsets + __builtin_amdgcn_readfirstlane(u + 1)) - (int64_t)(u + 1) * a.out_map.cum;
+        return (int64_t)(u + 1) * t_out;
+    };
+    while (t.m0 >= st.off_next && st.u_tile < n_last) {
+        st.u_tile = __builtin_amdgcn_readfirstlane(st.u_tile + 1);
+        st.off_next = next_off(st.u_tile);
+    }
+    const int rl = grp * 32 * t.mr + st.row_in_group;     // row of this lane's acc-row-0 piece, relative to m0
+    const int64_t p = t.m0 + rl;
+    int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+    int u = st.u_tile;
+    int64_t nxt = st.off_next;
+    const int64_t t_end = t.m0 + 64 * t.mr;
+    while (nxt < t_end && u < n_last) {
+        c0 += (p >= nxt) ? 1 : 0;
+        c1 += (p + 32 >= nxt) ? 1 : 0;
+        c2 += (p + 64 >= nxt) ? 1 : 0;
+        c3 += (p + 96 >= nxt) ? 1 : 0;
+        u = __builtin_amdgcn_readfirstlane(u + 1);
+        nxt = next_off(u);
+    }
+    const int rb = a.ldx * 2;
+    const int base = rl * rb + st.a_chunk;
+    st.av0 = base + (st.u_tile + c0) * a.span * rb;
+    st.av1 = base + 32 * rb + (st.u_tile + c1) * a.span * rb;
+    st.av2 = base + 64 * rb + (st.u_tile + c2) * a.span * rb;
+    st.av3 = base + 96 * rb + (st.u_tile + c3) * a.span * rb;
+    st.xrsrc = make_srd(static_cast<const char*>(a.X) + t.m0 * (int64_t)a.ldx * 2);
+}
+
+__device__ __forceinline__ void set_rows(const TdnnArgs& a, const Tile& t, int grp, Stream& st) {
+    if (a.out_map.offsets == nullptr) set_rows<false>(a, t, grp, st);
+    else set_rows<true>(a, t, grp, st);
+}
+
+// Scalar source offset of the activation K-tiles, stepped one K-tile at a time (taps innermost:
+// tap 0, 1, .., then the next 64-channel block): no division in the loop.
+struct KPos {
+    int tap, so;
+};
+__device__ __forceinline__ void kstep(const TdnnArgs& a, KPos& k) {
+    const int tapstep = a.tap_rows * a.ldx * 2;
+    if (k.tap + 1 < a.n_taps) {
+        k.tap += 1;
+        k.so += tapstep;
+    } else {
+        k.so += 128 - k.tap * tapstep;
+        k.tap = 0;
+    }
+}
+
+// --- DMA piece groups of one wave (buffer b_ = parity of the K-tile) -------------------------
+// W: the wave's four pieces (channel rows 8*(wave + 8t) ..+7); A01 / A23: its piece of acc rows 0,1 / 2,(3)
+#define PP_ISSUE_W(b_, q_)                                                          \
+    {                                                                               \
+        const int so_ = (q_) * 128;                                                 \
+        dma16(st.wrsrc, st.lds_w + (b_) * kBufBytes, st.wv0, so_);                  \
+        dma16(st.wrsrc, st.lds_w + (b_) * kBufBytes + 8 * 1024, st.wv0, so_ + st.w64);       \
+        dma16(st.wrsrc, st.lds_w + (b_) * kBufBytes + 16 * 1024, st.wv0, so_ + 2 * st.w64);  \
+        dma16(st.wrsrc, st.lds_w + (b_) * kBufBytes + 24 * 1024, st.wv0, so_ + 3 * st.w64);  \
+    }
+#define PP_ISSUE_A01(b_, so_)                                                       \
+    {                                                                               \
+        dma16(st.xrsrc, st.lds_a + (b_) * kBufBytes, st.av0, so_);                  \
+        dma16(st.xrsrc, st.lds_a + (b_) * kBufBytes + kAccRowB, st.av1, so_);       \
+    }
+#define PP_ISSUE_A23(MR_, b_, so_)                                                  \
+    {                                                                               \
+        dma16(st.xrsrc, st.lds_a + (b_) * kBufBytes + 2 * kAccRowB, st.av2, so_);   \
+        if ((MR_) > 3) dma16(st.xrsrc, st.lds_a + (b_) * kBufBytes + 3 * kAccRowB, st.av3, so_); \
+    }
+
+// first K-tiles of a tile: part 1 = all of K-tile 0; part 2 = all of K-tile 1, in the K loop's request order
+// (acc rows 0,1, then W, then acc rows 2,3), which keeps the loop's counted waits uniform from the first K-tile
+__device__ __forceinline__ void issue_head1(const TdnnArgs& a, const Stream& st, int mr) {
+    PP_ISSUE_W(0, 0)
+    PP_ISSUE_A01(0, 0)
+    PP_ISSUE_A23(mr, 0, 0)
+}
+__device__ __forceinline__ void issue_head2(const TdnnArgs& a, const Stream& st, int mr) {
+    KPos k1 = {0, 0};
+    kstep(a, k1);
+    PP_ISSUE_A01(1, k1.so)
+    PP_ISSUE_W(1, 1)
+    PP_ISSUE_A23(mr, 1, k1.so)
+}
+
+struct Lane {
+    int h, r;
+    int rd;          // r*128: row part of every fragment read
+    int k0, k1, k2, k3;   // swizzled byte offset of this lane's 16-byte chunk for k-steps 0..3
+    unsigned a_rd;   // LDS byte offset (buffer 0) of this wave's group's acc row 0, + rd
+    unsigned w_rd;   // LDS byte offset (buffer 0) of this wave's channel column 0, + rd
+    int wave, grp, wc;
+};
+
+#define PP_RD(dst_, off_) if constexpr (!PP_KNOCK_RD) dst_ = *reinterpret_cast<const float4*>(smem + (off_));
+#define PP_RDW(dst_, off_) if constexpr (!PP_KNOCK_RDW) PP_RD(dst_, off_)
+// W fragments of K-tile in buffer b_: 2 columns x 4 k-steps
+#define PP_READ_W(b_)                                                     \
+    {                                                                     \
+        const unsigned o_ = ln.w_rd + (b_) * kBufBytes;                   \
+        PP_RDW(wf0_0, o_ + ln.k0) PP_RDW(wf0_1, o_ + ln.k1) PP_RDW(wf0_2, o_ + ln.k2) PP_RDW(wf0_3, o_ + ln.k3)              \
+        PP_RDW(wf1_0, o_ + kAccRowB + ln.k0) PP_RDW(wf1_1, o_ + kAccRowB + ln.k1)                                         \
+        PP_RDW(wf1_2, o_ + kAccRowB + ln.k2) PP_RDW(wf1_3, o_ + kAccRowB + ln.k3)                                         \
+    }
+// A fragments of acc row i_ into fragment set f_
+#define PP_READ_A(f_, i_, b_)                                             \
+    {                                                                     \
+        const unsigned o_ = ln.a_rd + (b_) * kBufBytes + (i_) * kAccRowB; \
+        PP_RD(af##f_##_0, o_ + ln.k0) PP_RD(af##f_##_1, o_ + ln.k1) PP_RD(af##f_##_2, o_ + ln.k2) PP_RD(af##f_##_3, o_ + ln.k3) \
+    }
+// one MFMA: accumulator (row i_, column j_), A fragment set f_, k-step s_.  Store variant: the weights
+// are the MFMA A operand (channels -> accumulator registers); pooling variant: the activations are.
+#define PP_MF(i_, j_, f_, s_)                                                                                      \
+    if constexpr (POOL)                                                                                            \
+        acc##i_##j_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af##f_##_##s_),           \
+                                                              __builtin_bit_cast(bf16x8, wf##j_##_##s_), acc##i_##j_, 0, 0, 0); \
+    else                                                                                                           \
+        acc##i_##j_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf##j_##_##s_),           \
+                                                              __builtin_bit_cast(bf16x8, af##f_##_##s_), acc##i_##j_, 0, 0, 0);
+
+// One MFMA step (k-step s_) of acc rows i0_, i1_ (fragment sets of the same number) x both columns
+#define PP_MF4(i0_, i1_, s_) PP_MF(i0_, 0, i0_, s_) PP_MF(i0_, 1, i0_, s_) PP_MF(i1_, 0, i1_, s_) PP_MF(i1_, 1, i1_, s_)
+#define PP_MF2(i0_, s_) PP_MF(i0_, 0, i0_, s_) PP_MF(i0_, 1, i0_, s_)
+// a single MFMA (acc row i_, column j_, k-step s_; fragment set = row), to be followed by ONE LDS read: a
+// ds_read_b128 holds the wave's issue for ~30 cycles (stamps, profiles/diag/pp_stamps.py), which is free
+// exactly when an MFMA of this wave is executing (32 cycles) -- so reads and MFMAs alternate one to one
+#define PP_M1(i_, j_, s_) PP_MF(i_, j_, i_, s_) SB();
+// one fragment read: acc row i_ (= fragment set i_), k-step s_, from buffer b_
+#define PP_RA(i_, s_, b_) if constexpr (!PP_KNOCK_RDA) PP_RD(af##i_##_##s_, ln.a_rd + (b_) * kBufBytes + (i_) * kAccRowB + ln.k##s_)
+
+// One K-tile held in LDS buffer b_ (odd_ = its parity).  `last` = one of the tile's last two K-tiles
+// (nothing left to request two K-tiles ahead); k2.so = activation source offset of K-tile q+2.
+//   load 0:  read the 8 W fragments; request acc rows 0,1 of K-tile q+2
+//   mfma 0:  MR=4: acc rows 0,1 (16 MFMAs); MR=3: acc rows 0,1, k-steps 0-2 (12) -- with the fragment reads of
+//            acc rows 2,(3) behind its first MFMAs
+//   load 1:  request W and acc rows 2,(3) of K-tile q+2
+//   mfma 1:  MR=4: acc rows 2,3 (16); MR=3: acc rows 0,1 k-step 3 then acc row 2 (12) -- with the fragment reads
+//            of acc rows 0,1 of K-tile q+1 behind the acc row 2 MFMAs
+// The two segments of a wave are equally long, so the SIMD partner's load segments have the same time to
+// hide in.  Activation fragments are never read in a load segment, and never two reads behind one MFMA.
+// Every segment ends with lgkmcnt(0) before its barrier (a slot may be refilled in any later segment).
+// Counted vmcnt at the end of a load segment (request order per wave: [rows 0,1] | [W, rows 2,3] | ...):
+//   load 0 must have acc rows 2,3 of K-tile q   (requested three load segments ago): MR+6 younger pieces
+//   load 1 must have W of K-tile q+1 (two load segments ago) and rows 0,1 of q+1 (three): 2*MR+2 younger
+// -- never a drain; at the tail of a tile the counts shrink with the requests that are no longer made.
+#define PP_KTILE(b_, odd_)                                                          \
+    {                                                                               \
+        SB();                                                                       \
+        PP_READ_W(b_)                                                               \
+        SB();                                                                       \
+        if (!last && !PP_KNOCK_DMA) PP_ISSUE_A01(b_, k2.so)                         \
+        SB();                                                                       \
+        PP_WAIT_LGKM();                                                             \
+        PP_STAMP(0)                                                                 \
+        if (!last) { if (MR == 4) { PP_WAIT_VM(10); } else { PP_WAIT_VM(9); } }     \
+        else if (!(odd_)) { if (MR == 4) { PP_WAIT_VM(8); } else { PP_WAIT_VM(7); } } \
+        else { PP_WAIT_VM(0); }                                                     \
+        PP_STAMP(1)                                                                 \
+        PP_BARRIER()                                                                \
+        PP_STAMP(2)                                                                 \
+        __builtin_amdgcn_s_setprio(1);                                              \
+        PP_M1(0, 0, 0) PP_RA(2, 0, b_) SB(); PP_M1(0, 1, 0) PP_RA(2, 1, b_) SB();   \
+        PP_M1(1, 0, 0) PP_RA(2, 2, b_) SB(); PP_M1(1, 1, 0) PP_RA(2, 3, b_) SB();   \
+        if constexpr (MR == 4) {                                                    \
+            PP_M1(0, 0, 1) PP_RA(3, 0, b_) SB(); PP_M1(0, 1, 1) PP_RA(3, 1, b_) SB(); \
+            PP_M1(1, 0, 1) PP_RA(3, 2, b_) SB(); PP_M1(1, 1, 1) PP_RA(3, 3, b_) SB(); \
+            PP_MF4(0, 1, 2) SB(); PP_MF4(0, 1, 3) SB();                             \
+        } else {                                                                    \
+            PP_MF4(0, 1, 1) SB(); PP_MF4(0, 1, 2) SB();                             \
+        }                                                                           \
+        __builtin_amdgcn_s_setprio(0);                                              \
+        PP_WAIT_LGKM();                                                             \
+        PP_STAMP(3)                                                                 \
+        PP_BARRIER()                                                                \
+        PP_STAMP(4)                                                                 \
+        if (!last && !PP_KNOCK_DMA) {                                               \
+            PP_ISSUE_W(b_, q + 2 + (odd_ ? 1 : 0))                                  \
+            PP_ISSUE_A23(MR, b_, k2.so)                                             \
+        }                                                                           \
+        SB();                                                                       \
+        PP_STAMP(6)                                                                 \
+        if (!last) { if (MR == 4) { PP_WAIT_VM(10); } else { PP_WAIT_VM(8); } }     \
+        else if (!(odd_)) { if (MR == 4) { PP_WAIT_VM(2); } else { PP_WAIT_VM(1); } } \
+        else { PP_WAIT_VM(0); }                                                     \
+        PP_STAMP(7)                                                                 \
+        PP_BARRIER()                                                                \
+        PP_STAMP(8)                                                                 \
+        __builtin_amdgcn_s_setprio(1);                                              \
+        if constexpr (MR == 3) { PP_MF4(0, 1, 3) SB(); }                            \
+        /* (after the tile's last K-tile these reads fetch stale bytes that nobody uses: cheaper than a branch */ \
+        /*  around the MFMAs, which made hipcc keep two register assignments alive and spill) */ \
+        PP_M1(2, 0, 0) PP_RA(0, 0, (b_) ^ 1) SB(); PP_M1(2, 1, 0) PP_RA(0, 1, (b_) ^ 1) SB(); \
+        PP_M1(2, 0, 1) PP_RA(0, 2, (b_) ^ 1) SB(); PP_M1(2, 1, 1) PP_RA(0, 3, (b_) ^ 1) SB(); \
+        PP_M1(2, 0, 2) PP_RA(1, 0, (b_) ^ 1) SB(); PP_M1(2, 1, 2) PP_RA(1, 1, (b_) ^ 1) SB(); \
+        PP_M1(2, 0, 3) PP_RA(1, 2, (b_) ^ 1) SB(); PP_M1(2, 1, 3) PP_RA(1, 3, (b_) ^ 1) SB(); \
+        if constexpr (MR == 4) {                                                    \
+            PP_MF2(3, 0) PP_MF2(3, 1) PP_MF2(3, 2) PP_MF2(3, 3) SB();               \
+        }                                                                           \
+        __builtin_amdgcn_s_setprio(0);                                              \
+        PP_WAIT_LGKM();                                                             \
+        PP_STAMP(9)                                                                 \
+        PP_BARRIER()                                                                \
+        PP_STAMP(10)                                                                \
+        kstep(a, k2);                                                               \
+    }
+
+// ReLU + folded BatchNorm on one accumulator whose REGISTERS are channels (store variant): element e =
+// channel (e&3) + 8*(e>>2) + 4*h of the 32-channel block.  The bias is already inside (the accumulators
+// start at it); scale / shift of the lane's 16 channels are passed in registers, read from LDS once per
+// column and tile (an LDS read holds a wave's issue ~30-40 cycles: twelve per accumulator were the
+// largest single item of this epilogue).
+__device__ __forceinline__ void store_acc(const f32x16& v, const float4 (&sc)[4], const float4 (&sh)[4],
+                                          __amdgpu_buffer_rsrc_t yrsrc, int y_voff, int y_soff) {
+    unsigned pk[8];
+    typedef float f32x2v __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+        const float y0 = fmaf(fmaxf(v[4 * gq + 0], 0.f), sc[gq].x, sh[gq].x);
+        const float y1 = fmaf(fmaxf(v[4 * gq + 1], 0.f), sc[gq].y, sh[gq].y);
+        const float y2 = fmaf(fmaxf(v[4 * gq + 2], 0.f), sc[gq].z, sh[gq].z);
+        const float y3 = fmaf(fmaxf(v[4 * gq + 3], 0.f), sc[gq].w, sh[gq].w);
+        pk[2 * gq] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{y0, y1}, bf16x2));
+        pk[2 * gq + 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{y2, y3}, bf16x2));
+    }
+    // lane halves hold channels 8g..8g+3 (h=0) and 8g+4..8g+7 (h=1) of register group g: swapping the
+    // upper half of group g with the lower half of group g+1 leaves 8 consecutive channels per lane
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) {
+        auto r0 = __builtin_amdgcn_permlane32_swap(pk[4 * pr + 0], pk[4 * pr + 2], false, false);
+        auto r1 = __builtin_amdgcn_permlane32_swap(pk[4 * pr + 1], pk[4 * pr + 3], false, false);
+        const u32x4 o = {r0[0], r1[0], r0[1], r1[1]};
+        __builtin_amdgcn_raw_buffer_store_b128(o, yrsrc, y_voff, y_soff + pr * 32, 0);
+    }
+}
+
+// Fused statistics pooling for the pooling variant (main.py:59-63), frames in the accumulator registers and
+// the channel on the lane.  The epilogue runs in the open here (both waves of a SIMD are in it at the same
+// time, the matrix pipe idles), so it is as short as the arithmetic allows: per (32-frame group, utterance)
+// and channel the RAW sums S1 = sum r, S2 = sum r^2 of r = relu(z + bias) over the utterance's frames in the
+// group -- one v_max, one add and one fma per value.  Scale and shift of the folded BatchNorm are applied
+// by pool_finalize (mean = shift + scale*S1/n, std = |scale|*sqrt((S2 - S1^2/n)/(n-1)) with the totals and
+// the difference taken in fp64); r >= 0 keeps the cancellation in S2 - S1^2/n mild (relative error of the
+// variance ~1e-7*(1 + mean^2/var)), far inside this bf16 path's 1e-2 bar.
+// v0 / v1: the accumulators of this wave's two 32-channel columns for the group at compact row row_g
+// (bias already inside: the accumulators start at it).
+// Returns true when the group lay inside one utterance (exactly four stores were issued).
+// RAGGED is a template parameter and the utterance index is kept provably wave-uniform on purpose: with
+// a run-time "offsets ? load : multiply" hipcc emitted VECTOR loads of the offsets followed by
+// s_waitcnt vmcnt(0) -- on the fixed-length path too -- and every one of those waits drained the DMA
+// queue (the next tile's first K-tiles) in the middle of the epilogue.
+template <bool RAGGED>
+__device__ __forceinline__ int64_t first_row(const RowMap& m, int u) {
+    u = __builtin_amdgcn_readfirstlane(u);
+    if (RAGGED) return sload_i64(m.offsets + u) - (int64_t)u * m.cum;
+    return (int64_t)u * (m.fixed_T - m.cum);
+}
+template <bool RAGGED>
+__device__ __forceinline__ bool pool_raw_pair(const TdnnArgs& a, const f32x16& v0, const f32x16& v1, int64_t row_g,
+                                              int h, int col0, PoolCur& pc) {
+    const RowMap& m = a.out_map;
+    while (pc.end <= row_g && pc.u < m.n_utts - 1) {
+        pc.u = __builtin_amdgcn_readfirstlane(pc.u + 1);
+        pc.end = first_row<RAGGED>(m, pc.u + 1);
+    }
+    const int64_t grp = row_g >> 5;
+    const int ld = a.ldy;
+    if (pc.end >= row_g + 32) {               // the whole group belongs to utterance pc.u
+        // two values per instruction where the ISA has one (v_pk_add_f32 / v_pk_fma_f32; the max has none)
+        f32x2 p1a = {0.f, 0.f}, p2a = {0.f, 0.f}, p1b = {0.f, 0.f}, p2b = {0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 16; e += 2) {
+            const f32x2 ra = {fmaxf(v0[e], 0.f), fmaxf(v0[e + 1], 0.f)};
+            const f32x2 rb = {fmaxf(v1[e], 0.f), fmaxf(v1[e + 1], 0.f)};
+            p1a += ra;
+            p2a = __builtin_elementwise_fma(ra, ra, p2a);
+            p1b += rb;
+            p2b = __builtin_elementwise_fma(rb, rb, p2b);
+        }
+        const float s1a = add_halves(p1a.x + p1a.y), s2a = add_halves(p2a.x + p2a.y);
+        const float s1b = add_halves(p1b.x + p1b.y), s2b = add_halves(p2b.x + p2b.y);
+        if (h == 0) {
+            float* part = a.pool_part + (grp + pc.u) * (int64_t)(2 * ld);
+            part[col0] = s1a;
+            part[ld + col0] = s2a;
+            part[col0 + 32] = s1b;
+            part[ld + col0 + 32] = s2b;
+        }
+        return true;
+    }
+    for (int u = pc.u; u < m.n_utts; ++u) {   // the group straddles utterances: select each one's rows
+        const int64_t off = first_row<RAGGED>(m, u);
+        if (off >= row_g + 32) break;
+        const int64_t end = first_row<RAGGED>(m, u + 1);
+        const int64_t lo_r = off > row_g ? off : row_g;
+        const int64_t hi_r = end < row_g + 32 ? end : row_g + 32;
+        if (hi_r <= lo_r) continue;
+        const int lo_l = (int)(lo_r - row_g), hi_l = (int)(hi_r - row_g);
+        const unsigned below_hi = hi_l >= 32 ? 0xffffffffu : ((1u << hi_l) - 1u);
+        const unsigned lm = (below_hi & ~((1u << lo_l) - 1u)) >> (4 * h);   // this lane's rows: bits (e&3) + 8*(e>>2)
+        float s1a = 0.f, s2a = 0.f, s1b = 0.f, s2b = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const bool in = (lm >> ((e & 3) + 8 * (e >> 2))) & 1u;      // a SELECT: rows outside may hold anything
+            const float ra = in ? fmaxf(v0[e], 0.f) : 0.f, rb = in ? fmaxf(v1[e], 0.f) : 0.f;
+            s1a += ra;
+            s2a = fmaf(ra, ra, s2a);
+            s1b += rb;
+            s2b = fmaf(rb, rb, s2b);
+        }
+        s1a = add_halves(s1a);
+        s2a = add_halves(s2a);
+        s1b = add_halves(s1b);
+        s2b = add_halves(s2b);
+        if (h == 0) {
+            float* part = a.pool_part + (grp + u) * (int64_t)(2 * ld);
+            part[col0] = s1a;
+            part[ld + col0] = s2a;
+            part[col0 + 32] = s1b;
+            part[ld + col0 + 32] = s2b;
+        }
+    }
+    return false;
+}
+
+// One tile: K loop, request of the next tile's first K-tiles, epilogue.
+template <int MR, bool POOL>
+__device__ __forceinline__ void process_tile(const TdnnArgs& a, char* smem, Stream& st, const Lane& ln, const Tile& t,
+                                             const Tile& nxt, bool has_next, int n0, int nk, PoolCur& pc, float bi0,
+                                             float bi1) {
+    // the accumulators start at the bias: of their lane's channel (pooling variant: channel on the lane), or of
+    // each register's channel (store variant: 16 channels per lane and column, from the LDS copy)
+    f32x16 acc00, acc01, acc10, acc11, acc20, acc21, acc30, acc31;
+    if constexpr (POOL) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            acc00[e] = bi0; acc01[e] = bi1; acc10[e] = bi0; acc11[e] = bi1;
+            acc20[e] = bi0; acc21[e] = bi1; acc30[e] = bi0; acc31[e] = bi1;
+        }
+    } else {
+        const char* cb = smem + kConstOff + (ln.wc * 64 + 4 * ln.h) * 4;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const float4 b0 = *reinterpret_cast<const float4*>(cb + gq * 32);
+            const float4 b1 = *reinterpret_cast<const float4*>(cb + 128 + gq * 32);
+            acc00[4 * gq] = b0.x; acc00[4 * gq + 1] = b0.y; acc00[4 * gq + 2] = b0.z; acc00[4 * gq + 3] = b0.w;
+            acc01[4 * gq] = b1.x; acc01[4 * gq + 1] = b1.y; acc01[4 * gq + 2] = b1.z; acc01[4 * gq + 3] = b1.w;
+        }
+        acc10 = acc00; acc20 = acc00; acc30 = acc00;
+        acc11 = acc01; acc21 = acc01; acc31 = acc01;
+    }
+    float4 wf0_0, wf0_1, wf0_2, wf0_3, wf1_0, wf1_1, wf1_2, wf1_3;
+    float4 af0_0, af0_1, af0_2, af0_3, af1_0, af1_1, af1_2, af1_3;     // acc rows 0,1 (read during the previous mfma 1)
+    float4 af2_0, af2_1, af2_2, af2_3, af3_0, af3_1, af3_2, af3_3;     // acc rows 2,3 (read during mfma 0)
+#ifdef XVEC_DIAG
+    unsigned long long dsum[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long dprev, dstart;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dstart)::"memory");
+#endif
+
+#ifdef XVEC_KNOCK
+    if (PP_KNOCK_RD || PP_KNOCK_RDW || PP_KNOCK_RDA) {
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        wf0_0 = wf0_1 = wf0_2 = wf0_3 = wf1_0 = wf1_1 = wf1_2 = wf1_3 = z;
+        af0_0 = af0_1 = af0_2 = af0_3 = af1_0 = af1_1 = af1_2 = af1_3 = z;
+        af2_0 = af2_1 = af2_2 = af2_3 = af3_0 = af3_1 = af3_2 = af3_3 = z;
+    }
+#endif
+    // K-tile 0 complete: its pieces are older than the MR+4 of K-tile 1 and than the stores the previous
+    // tile's epilogue issued behind them -- count those instead of waiting for them (unknown count: wait)
+    {
+        const int ps = st.pending_stores;
+        if (ps == 16) { if (MR == 4) { PP_WAIT_VM(24); } else { PP_WAIT_VM(23); } }
+        else if (ps == 12) { if (MR == 4) { PP_WAIT_VM(20); } else { PP_WAIT_VM(19); } }
+        else if (ps == 0) { if (MR == 4) { PP_WAIT_VM(8); } else { PP_WAIT_VM(7); } }
+        else { PP_WAIT_VM(0); }
+    }
+    PP_BARRIER()
+    if (ln.grp == 1) PP_BARRIER()          // ping-pong: the second group runs one barrier behind
+#ifdef XVEC_DIAG
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dprev)::"memory");
+    dsum[12] += dprev - dstart;            // head wait
+#endif
+    // acc rows 0,1 of K-tile 0: the only activation fragments read outside an MFMA segment
+    PP_RA(0, 0, 0) PP_RA(0, 1, 0) PP_RA(0, 2, 0) PP_RA(0, 3, 0)
+    PP_RA(1, 0, 0) PP_RA(1, 1, 0) PP_RA(1, 2, 0) PP_RA(1, 3, 0)
+    PP_WAIT_LGKM();                         // (their slots are the first ones the loop refills)
+    KPos k2 = {0, 0};                       // K-tile q+2
+    kstep(a, k2);
+    kstep(a, k2);
+    for (int q = 0; q < nk; q += 2) {
+        const bool last = q + 2 >= nk;
+        PP_KTILE(0, false)
+        PP_KTILE(1, true)
+    }
+    if (ln.grp == 0) PP_BARRIER()
+    PP_STAMP(13)                            // tail barrier
+    // every wave is past its last LDS read: both buffers are free.  The next tile's first two K-tiles are
+    // requested before the epilogue (the DMA flies under it); the epilogue's stores are then the youngest
+    // entries of the vector-memory queue, and the next tile's first wait counts them (st.pending_stores,
+    // -1 = unknown: wait for everything) instead of waiting for them.
+    if (has_next) {
+        set_rows(a, nxt, ln.grp, st);
+        issue_head1(a, st, nxt.mr);
+        issue_head2(a, st, nxt.mr);
+    }
+    PP_STAMP(5)                             // rows + first K-tiles of the next tile
+
+    const int64_t row0 = t.m0 + ln.grp * 32 * MR;
+    int n_st = 0;
+    if constexpr (PP_KNOCK_EPI) {
+        asm volatile("" ::"v"(acc00), "v"(acc01), "v"(acc10), "v"(acc11), "v"(acc20), "v"(acc21), "v"(acc30), "v"(acc31));
+    } else if constexpr (!POOL) {
+        const __amdgpu_buffer_rsrc_t yrsrc = make_rsrc(static_cast<char*>(a.Y) + (t.m0 * (int64_t)a.ldy + n0) * 2);
+        const int y_voff = (ln.r * a.ldy + ln.wc * 64 + 8 * ln.h) * 2;
+        const char* cst = smem + kConstOff + (ln.wc * 64 + 4 * ln.h) * 4;
+#define PP_STORE(i_, j_)                                                                               \
+        if (MR > i_ && row0 + 32 * i_ < t.valid_end) {                                                    \
+            store_acc(acc##i_##j_, sc, sh, yrsrc, y_voff, (ln.grp * 32 * MR + 32 * i_) * a.ldy * 2 + 64 * j_); \
+            n_st += 2;                                                                                    \
+        }
+        {
+            float4 sc[4], sh[4];
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                sc[gq] = *reinterpret_cast<const float4*>(cst + 1024 + gq * 32);
+                sh[gq] = *reinterpret_cast<const float4*>(cst + 2048 + gq * 32);
+            }
+            PP_STORE(0, 0) PP_STORE(1, 0) PP_STORE(2, 0) PP_STORE(3, 0)
+        }
+        {
+            float4 sc[4], sh[4];
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                sc[gq] = *reinterpret_cast<const float4*>(cst + 128 + 1024 + gq * 32);
+                sh[gq] = *reinterpret_cast<const float4*>(cst + 128 + 2048 + gq * 32);
+            }
+            PP_STORE(0, 1) PP_STORE(1, 1) PP_STORE(2, 1) PP_STORE(3, 1)
+        }
+#undef PP_STORE
+    } else {
+        const int col0 = n0 + ln.wc * 64 + ln.r;
+        bool regular = true;
+#define PP_POOL(RG_, i_)                                                                               \
+        if (MR > i_ && row0 + 32 * i_ < t.valid_end) {                                                    \
+            regular &= pool_raw_pair<RG_>(a, acc##i_##0, acc##i_##1, row0 + 32 * i_, ln.h, col0, pc);     \
+            n_st += 4;                                                                                    \
+        }
+        if (a.out_map.offsets == nullptr) {
+            PP_POOL(false, 0) PP_POOL(false, 1) PP_POOL(false, 2) PP_POOL(false, 3)
+        } else {
+            PP_POOL(true, 0) PP_POOL(true, 1) PP_POOL(true, 2) PP_POOL(true, 3)
+        }
+#undef PP_POOL
+        if (!regular) n_st = -1;
+    }
+    st.pending_stores = n_st;
+#ifdef XVEC_DIAG
+    {
+        unsigned long long dend;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dend)::"memory");
+        dsum[11] += dend - dprev;          // epilogue + second K-tile of the next tile
+        dsum[14] += 1;
+        dsum[15] += (unsigned long long)MR;
+        if ((ln.wave & 3) == 0 && ln.r == 0 && ln.h == 0 && blockIdx.x < 512) {
+            _Pragma("unroll") for (int k = 0; k < 16; ++k) g_pp_diag[(POOL ? 512 * 32 : 0) + blockIdx.x * 32 + ln.grp * 16 + k] += dsum[k];
+        }
+    }
+#endif
+}
+
+template <bool POOL>
+__global__ __launch_bounds__(kThreads, 2) void tdnn_pp_kernel(const TdnnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int jcol = lid % a.n_tiles;                   // 256-channel column
+    const int prange = lid / a.n_tiles;
+    const int64_t u_begin = a.groups_total * (int64_t)prange / a.blocks_per_col;     // 64-frame units
+    const int64_t u_end = a.groups_total * (int64_t)(prange + 1) / a.blocks_per_col;
+    const int n0 = jcol * 256;
+    const int nk = a.n_taps * a.cpt;                    // K-tiles of 64 (even)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    Lane ln;
+    ln.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    ln.grp = ln.wave >> 2;
+    ln.wc = ln.wave & 3;
+    ln.h = lane >> 5;
+    ln.r = lane & 31;
+    ln.rd = ln.r * kRowB;
+    {
+        const int sw = (ln.r >> 1) & 7;
+        ln.k0 = ((0 + ln.h) ^ sw) << 4;
+        ln.k1 = ((2 + ln.h) ^ sw) << 4;
+        ln.k2 = ((4 + ln.h) ^ sw) << 4;
+        ln.k3 = ((6 + ln.h) ^ sw) << 4;
+    }
+    ln.a_rd = ln.grp * 4 * kAccRowB + ln.rd;
+    ln.w_rd = kABytes + ln.wc * 2 * kAccRowB + ln.rd;
+
+    // per-channel constants of the block's column -> LDS (store variant reads them per register)
+    if (tid < 192) {
+        const int arr = tid >> 6, c4 = (tid & 63) * 4;
+        const float* src = arr == 0 ? a.bias : arr == 1 ? a.scale : a.shift;
+        *reinterpret_cast<float4*>(smem + kConstOff + arr * 1024 + c4 * 4) = *reinterpret_cast<const float4*>(src + n0 + c4);
+    }
+    float bi0 = 0.f, bi1 = 0.f;
+    if (POOL) {
+        const int c = n0 + ln.wc * 64 + ln.r;
+        bi0 = a.bias[c];
+        bi1 = a.bias[c + 32];
+    }
+
+    // DMA map of this wave: piece row = lane >> 3 (8 rows per piece), LDS position lane & 7 holds the
+    // source chunk (lane & 7) ^ swizzle(row), swizzle = (row >> 1) & 7 of the row's index in its 32-row block
+    Stream st;
+    const int prow = lane >> 3, ppos = lane & 7;
+    {
+        const int rr = ln.wc * 8 + prow;                                  // A: row within the 32-frame acc row
+        st.row_in_group = rr;
+        st.a_chunk = (ppos ^ ((rr >> 1) & 7)) * 16;
+        st.lds_a = (unsigned)(unsigned long long)(lds_ptr)(smem) + ln.grp * 4 * kAccRowB + ln.wc * 1024;
+        const int wr = ln.wave * 8 + prow;                                // W: channel row of piece t = wr + 64*t
+        const int w_chunk = (ppos ^ ((wr >> 1) & 7)) * 16;                // ((wr + 64t) >> 1) & 7 is the same for every t
+        st.lds_w = (unsigned)(unsigned long long)(lds_ptr)(smem) + kABytes + ln.wave * 1024;
+        const int kb = a.k_pad * 2;
+        st.wv0 = wr * kb + w_chunk;
+        st.w64 = 64 * kb;
+        st.wrsrc = make_srd(static_cast<const char*>(a.W) + (int64_t)n0 * kb);
+        st.av0 = st.av1 = st.av2 = st.av3 = 0;
+        st.u_tile = __builtin_amdgcn_readfirstlane(utt_of_row(a.out_map, u_begin * 64));
+        st.off_next = row_off(a.out_map, st.u_tile + 1);
+        st.xrsrc = st.wrsrc;
+        PoolCur pc;
+        pc.u = 0;
+        pc.end = 0;
+
+        // tiles of this block: n units cut into ceil(n/4) tiles of 3 or 4 units, as equal as possible
+        // (n = 1, 2, 5 cannot be: the last tile then computes rows past the range and masks them)
+        const int n = (int)(u_end - u_begin);
+        if (n <= 0) return;
+        int nt = (n + 3) / 4;
+        int base = n / nt, extra = n % nt;
+        if (base < 3) { base = 3; extra = 0; nt = (n + 2) / 3; }
+        const int64_t range_end = u_end * 64;
+
+        auto tile_at = [&](int idx, int64_t m0) {
+            Tile t;
+            t.m0 = m0;
+            t.mr = idx < extra ? base + 1 : base;
+            t.valid_end = range_end;
+            return t;
+        };
+        Tile cur = tile_at(0, u_begin * 64);
+        if (POOL) pc = pool_cursor(a, cur.m0 + ln.grp * 32 * cur.mr);
+        set_rows(a, cur, ln.grp, st);
+        __syncthreads();                                   // constants visible; nobody reads LDS buffers yet
+        issue_head1(a, st, cur.mr);
+        issue_head2(a, st, cur.mr);
+        st.pending_stores = 0;
+        for (int idx = 0; idx < nt; ++idx) {
+            const bool has_next = idx + 1 < nt;
+            Tile nxt = cur;
+            if (has_next) nxt = tile_at(idx + 1, cur.m0 + 64 * cur.mr);
+            if (cur.mr == 4)
+                process_tile<4, POOL>(a, smem, st, ln, cur, nxt, has_next, n0, nk, pc, bi0, bi1);
+            else
+                process_tile<3, POOL>(a, smem, st, ln, cur, nxt, has_next, n0, nk, pc, bi0, bi1);
+            cur = nxt;
+        }
+    }
+}
+
+}  // namespace pp
+
+#ifdef XVEC_DIAG
+extern "C" int xvec_pp_diag_read(unsigned long long* host, int n_words, int reset) {
+    hipError_t e = hipMemcpyFromSymbol(host, HIP_SYMBOL(pp::g_pp_diag), (size_t)n_words * 8);
+    if (e == hipSuccess && reset) e = hipMemset(nullptr, 0, 0);
+    if (reset) {
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(pp::g_pp_diag)) == hipSuccess) (void)hipMemset(p, 0, sizeof(unsigned long long) * 2 * 512 * 32);
+    }
+    return (int)e;
+}
+#endif
+
+hipError_t launch_tdnn_pp(const TdnnArgs& a, bool pool, hipStream_t s) {
+    if (a.groups_total <= 0 || a.blocks_per_col <= 0 || a.blocks_per_col > a.groups_total || (a.cpt & 1) ||
+        a.n_tiles <= 0)
+        return hipErrorInvalidValue;
+    const int grid = a.blocks_per_col * a.n_tiles;
+    if (pool) {
+        static LdsOptIn opt;
+        if (hipError_t e = opt.ensure(reinterpret_cast<const void*>(pp::tdnn_pp_kernel<true>), pp::kLdsBytes); e != hipSuccess)
+            return e;
+        pp::tdnn_pp_kernel<true><<<dim3(grid), dim3(pp::kThreads), pp::kLdsBytes, s>>>(a);
+    } else {
+        static LdsOptIn opt;
+        if (hipError_t e = opt.ensure(reinterpret_cast<const void*>(pp::tdnn_pp_kernel<false>), pp::kLdsBytes); e != hipSuccess)
+            return e;
+        pp::tdnn_pp_kernel<false><<<dim3(grid), dim3(pp::kThreads), pp::kLdsBytes, s>>>(a);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace xvec

@@ -66,6 +66,8 @@ struct xvec_handle {
     TdnnGeom geo[XVEC_NUM_TDNN];
     TdnnGeom geo16[XVEC_NUM_TDNN];     // bf16 packing of layers 2-5: 64-element chunks (layer 1 stays fp32)
     void* Wp16[XVEC_NUM_TDNN];         // bf16, fragment-major
+    void* Wr16[XVEC_NUM_TDNN];         // bf16, row-major [n_pad][k_pad] (tdnn_pp.hip: both operands reach LDS by DMA)
+    bool use_pp;                       // large-batch bf16 mapping enabled (XVEC_PP=0 disables it: A/B runs)
     void* Wp48[XVEC_NUM_TDNN];         // bf16x3: per chunk W_hi then W_lo fragments (2x the size), fragment-major
     float* Wp[XVEC_NUM_TDNN];
     float* vec[XVEC_NUM_TDNN];         // bias | scale | shift, n_pad each
@@ -175,7 +177,8 @@ struct StageTimer {
 // x3: bf16x3 arithmetic -- X (and Y, when it is bf16) are two bf16 planes `x_plane` / `y_plane` bytes apart
 int run_tdnn(xvec_handle* h, int layer, TdnnVariant v, const void* X, int ldx, int64_t x_rows, void* Y,
              int64_t rows_out, const RowMap& out_map, float* part, hipStream_t s, bool x3 = false,
-             int64_t x_plane = 0, int64_t y_plane = 0) {
+             int64_t x_plane = 0, int64_t y_plane = 0, bool* raw_pool = nullptr) {
+    if (raw_pool) *raw_pool = false;
     const bool in16 = v == TdnnVariant::kBf16 || v == TdnnVariant::kBf16Pool || v == TdnnVariant::kBf16ToF32 ||
                       v == TdnnVariant::kBf16First || v == TdnnVariant::kBf16FirstToF32;
     const TdnnGeom& g = in16 ? h->geo16[layer] : h->geo[layer];
@@ -233,6 +236,24 @@ int run_tdnn(xvec_handle* h, int layer, TdnnVariant v, const void* X, int ldx, i
         a.x_bytes = x_rows > 0 ? x_plane + x_rows * (int64_t)ldx * 2 : 0;
     }
     StageTimer t(h, T_L1 + layer, s);
+    // bf16, wide layers, enough rows to give every CU at least three 64-frame units: the 256-channel
+    // ping-pong mapping (tdnn_pp.hip); everything else (small batches, layer 1, narrow models, fp32,
+    // bf16x3) runs the 128x128 kernel
+    if (h->use_pp && !x3 && layer > 0 && (v == TdnnVariant::kBf16 || v == TdnnVariant::kBf16Pool) && g.n_pad % 256 == 0) {
+        const int n_cols = g.n_pad / 256;
+        const int bpc = h->num_cu / n_cols;
+        const int64_t units = (rows_out + 63) / 64;
+        if (bpc >= 1 && units >= 3 * (int64_t)bpc) {
+            a.W = h->Wr16[layer];
+            a.n_tiles = n_cols;
+            a.blocks_per_col = bpc;
+            a.groups_total = units;
+            a.pair_period = 0;
+            HIP_TRY(launch_tdnn_pp(a, v == TdnnVariant::kBf16Pool, s));
+            if (raw_pool) *raw_pool = v == TdnnVariant::kBf16Pool;     // its pooling partials are raw sums
+            return XVEC_OK;
+        }
+    }
     HIP_TRY(launch_tdnn(a, v, s));
     return XVEC_OK;
 }
@@ -291,13 +312,14 @@ int forward_rows(xvec_handle* h, const float* x_rows, int ldx, const int64_t* of
         }
         in = x16;
     }
+    bool raw_pool = false;
     for (int l = 0; l < XVEC_NUM_TDNN; ++l) {
         map.cum += h->geo[l].ctx_span;
         const int64_t rows_out = p.total - (int64_t)B * map.cum;
         const TdnnVariant v = l == 0 ? v1 : l == 4 ? v5 : vm;
         void* out_buf = l == 4 ? nullptr : bufs[l & 1];
         if ((rc = run_tdnn(h, l, v, in, ld_in, l == 0 ? p.total : 0, out_buf, rows_out, map, l == 4 ? part : nullptr, s,
-                           x3, in_plane, l == 4 ? 0 : act_plane)))
+                           x3, in_plane, l == 4 ? 0 : act_plane, l == 4 ? &raw_pool : nullptr)))
             return rc;
         in = out_buf;
         ld_in = nh;
@@ -312,6 +334,8 @@ int forward_rows(xvec_handle* h, const float* x_rows, int ldx, const int64_t* of
         f.C = XVEC_POOL_CHANNELS;
         f.n_pad = h->geo[4].n_pad;
         f.sub_rows = 32;
+        f.scale = raw_pool ? h->vec[4] + f.n_pad : nullptr;
+        f.shift = raw_pool ? h->vec[4] + 2 * f.n_pad : nullptr;
         HIP_TRY(launch_pool_finalize(f, s));
     }
     const int xv = h->cfg.x_vector_size, K6 = 2 * XVEC_POOL_CHANNELS;
@@ -399,6 +423,8 @@ int xvec_create(const xvec_cfg* cfg, xvec_handle** out) {
         const char* e = getenv("XVEC_BLOCKS_PER_CU");   // diagnostic knob (profiles/ab_env.sh); 2 = what the LDS allows
         h->blocks_per_cu = e ? atoi(e) : 2;
         if (h->blocks_per_cu < 1) h->blocks_per_cu = 1;
+        const char* p = getenv("XVEC_PP");
+        h->use_pp = !(p && atoi(p) == 0);
     }
     h->cin_pad = round_up(cfg->input_size, 4);
     fill_geometry(h, h->geo, 2 * kBK);
@@ -406,6 +432,7 @@ int xvec_create(const xvec_cfg* cfg, xvec_handle** out) {
     for (int i = 0; i < XVEC_NUM_TDNN; ++i) {
         const TdnnGeom& g = h->geo[i];
         if (hipMalloc(&h->Wp16[i], (size_t)h->geo16[i].n_pad * h->geo16[i].k_pad * 2) != hipSuccess ||
+            hipMalloc(&h->Wr16[i], (size_t)h->geo16[i].n_pad * h->geo16[i].k_pad * 2) != hipSuccess ||
             hipMalloc(&h->Wp48[i], (size_t)h->geo16[i].n_pad * h->geo16[i].k_pad * 2 * 2) != hipSuccess ||
             hipMalloc(reinterpret_cast<void**>(&h->Wp[i]), (size_t)g.n_pad * g.k_pad * 4) != hipSuccess ||
             hipMalloc(reinterpret_cast<void**>(&h->vec[i]), (size_t)3 * g.n_pad * 4) != hipSuccess) {
@@ -444,6 +471,7 @@ void xvec_destroy(xvec_handle* h) {
     for (int i = 0; i < XVEC_NUM_TDNN; ++i) {
         if (h->Wp[i]) (void)hipFree(h->Wp[i]);
         if (h->Wp16[i]) (void)hipFree(h->Wp16[i]);
+        if (h->Wr16[i]) (void)hipFree(h->Wr16[i]);
         if (h->Wp48[i]) (void)hipFree(h->Wp48[i]);
         if (h->vec[i]) (void)hipFree(h->vec[i]);
     }
@@ -478,6 +506,7 @@ int xvec_load_tdnn(xvec_handle* h, int layer, const float* weight, const float* 
                              h->vec[layer], h->vec[layer] + g.n_pad, h->vec[layer] + 2 * g.n_pad,
                              static_cast<hipStream_t>(stream)));
     HIP_TRY(launch_pack_tdnn_bf16(weight, h->geo16[layer], h->Wp16[layer], static_cast<hipStream_t>(stream)));
+    HIP_TRY(launch_pack_tdnn_rows_bf16(weight, h->geo16[layer], h->Wr16[layer], static_cast<hipStream_t>(stream)));
     {
         TdnnGeom g3 = h->geo16[layer];
         g3.terms = 2;

@@ -7,7 +7,8 @@
 namespace xvec {
 
 constexpr int kBK = 32;          // K-chunk (fp32 elements) staged per main-loop step
-constexpr int kRowPadTail = 136; // readable rows past M_pad: a 4-group look-ahead fetch (128) + max tap reach (6)
+constexpr int kRowPadTail = 264; // readable rows past M_pad: a masked tile of tdnn_pp.hip may reach two 64-row units (+63 of
+                                 // rounding) past the last valid row, + max tap reach (6); tdnn_layer.hip's look-ahead needs 134
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 inline int64_t round_up64(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
@@ -121,6 +122,12 @@ enum class TdnnVariant {
     kBf16FirstToF32   // layer 1, guarded, bf16 -> fp32 (per-layer test entry in bf16x3)
 };
 hipError_t launch_tdnn(const TdnnArgs& a, TdnnVariant v, hipStream_t s);
+// Large-batch bf16 mapping (tdnn_pp.hip): 256-channel columns, 64-frame units.  Reads TdnnArgs with
+//   W = row-major bf16 [n_pad][k_pad] (K order as the fp32 packing, 64-element chunks), n_tiles = n_pad / 256,
+//   groups_total = ceil(rows / 64) units, blocks_per_col ranges per column (>= 3 units each for full speed).
+hipError_t launch_tdnn_pp(const TdnnArgs& a, bool pool, hipStream_t s);
+// row-major bf16 copy of the packed weights for it
+hipError_t launch_pack_tdnn_rows_bf16(const float* W, const TdnnGeom& geo, void* Wr16, hipStream_t s);
 
 struct PoolArgs {
     const float* X;          // [B][T][C]
@@ -135,6 +142,8 @@ struct PoolFinalizeArgs {
     float* out;              // [B][2C]
     RowMap map;              // row layout of the pooled activation (layer 5 output)
     int C, n_pad, sub_rows;
+    const float* scale;      // nullptr: partials are (mean, M2) of the finished activation (tdnn_layer.hip);
+    const float* shift;      // else: raw sums (S1, S2) of relu(z + bias) (tdnn_pp.hip), y = scale*r + shift
 };
 hipError_t launch_pool_finalize(const PoolFinalizeArgs& a, hipStream_t s);
 

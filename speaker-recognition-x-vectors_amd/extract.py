@@ -134,42 +134,47 @@ def to_records(x_vecs: torch.Tensor, labels, ids) -> List[tuple]:
     return [(i, int(l), np.array(v, dtype=np.float64)) for v, l, i in zip(host, labels, ids)]
 
 
-def stream_x_vectors(model, host_batches: Iterable[torch.Tensor], device=None, depth: int = 2):
+def stream_x_vectors(model, host_batches: Iterable[torch.Tensor], device=None, depth: int = 3):
     """Overlapped extraction from HOST batches: yields the fp32 [B, D] x-vectors of every batch as
     host tensors, in input order.
 
-    Batch k+1 is copied host->device on a side stream while batch k runs on the caller's current
-    stream; results stay on the device until `depth` younger batches have been enqueued and are
-    then fetched with one plain copy each on a third stream (by then the batch has long finished, so
-    the host never waits for compute).  Measured alternatives that lost on this ROCm stack
-    (profiles/diag/stream_probe*.py): non-blocking result copies into pinned buffers made their
-    enqueue block (3.65 vs 2.91 ms per batch), and results parked in pinned host buffers cost ~9 ms per
-    512 KiB when the CPU reads them back (uncached mapping).  Device input slots are a small ring
-    allocated once per shape (an allocation inside the loop would reach hipMalloc, which
-    synchronises the device).  Host batches may be pinned or pageable, and float64 (what the
-    reference's DataLoader yields, main.py:137): the cast to fp32 happens on the device, as in
-    test_step."""
+    Three streams, nothing in the loop blocks the host unless `depth` batches are already in flight:
+      * batch k+1 is copied host->device on a side stream while batch k runs on the caller's current
+        stream (device input slots: a ring of depth+1 buffers per shape, allocated once -- an allocation
+        inside the loop could reach hipMalloc, which synchronises the device);
+      * the result of batch k is copied device->host on a third stream, enqueued right behind the
+        batch's `done` event into a ring of pinned result buffers (non-blocking), and handed out
+        `depth` batches later -- or earlier, as soon as its copy is known to have landed
+        (event.query(), no wait) -- as an ordinary (pageable) clone, so the pinned slot can be reused.
+    Round 1 fetched every result with a host-blocking `.cpu()` behind an event wait; on the driver's
+    box that pipeline was slower than the plain loop (BENCH_r01: 78.0 k vs 80.2 k embeddings/s against
+    90.1 k resident), here it is not (profiles/diag/stream_probe3.py) -- host wake-up latencies differ
+    between boxes, so the loop must not depend on them.
+    Host batches may be pinned or pageable, and float64 (what the reference's DataLoader yields,
+    main.py:137): the cast to fp32 happens on the device, as in test_step."""
     dev = torch.device(device) if device is not None else next(model.parameters()).device
     if dev.type != "cuda":
         raise RuntimeError("stream_x_vectors: the model must live on a HIP device")
+    if depth < 1:
+        raise ValueError("stream_x_vectors: depth must be >= 1")
     compute = torch.cuda.current_stream(dev)
     h2d, d2h = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
-    n_in = depth + 1
-    slots = [None] * n_in      # device inputs
-    consumed = [None] * n_in   # event: the batch that read the slot has been computed
-    inflight = []              # (event, device result)
+    n_ring = depth + 1
+    slots = [None] * n_ring      # device inputs
+    consumed = [None] * n_ring   # event: the batch that read the slot has been computed
+    results = [None] * n_ring    # pinned host result buffers [rows, D]
+    inflight = []                # (landed event, pinned buffer, rows)
 
-    def retire():
-        ev, out = inflight.pop(0)
-        ev.synchronize()
-        with torch.cuda.stream(d2h):               # not the compute stream: there the copy would queue
-            return out.cpu()                       # behind the younger batches already enqueued
+    def harvest():
+        ev, buf, n = inflight.pop(0)
+        ev.synchronize()                           # returns at once when query() was already true
+        return buf[:n].clone()
 
     k = 0
     for xb in host_batches:
         if xb.device.type != "cpu":
             raise ValueError("stream_x_vectors: expected host tensors (device batches: call extract_x_vec directly)")
-        i = k % n_in
+        i = k % n_ring
         fresh = slots[i] is None or slots[i].shape != xb.shape or slots[i].dtype != xb.dtype
         if fresh:
             slots[i] = None
@@ -187,12 +192,21 @@ def stream_x_vectors(model, host_batches: Iterable[torch.Tensor], device=None, d
         done = torch.cuda.Event()
         done.record(compute)
         consumed[i] = done
-        inflight.append((done, out))
+        n, D = out.shape
+        if results[i] is None or results[i].shape[0] < n or results[i].shape[1] != D:
+            results[i] = torch.empty((max(n, 1), D), dtype=out.dtype).pin_memory()
+        with torch.cuda.stream(d2h):               # not the compute stream: there the copy would queue
+            d2h.wait_event(done)                   # behind the younger batches already enqueued
+            results[i][:n].copy_(out, non_blocking=True)
+            landed = torch.cuda.Event()
+            landed.record(d2h)
+        out.record_stream(d2h)                     # its memory returns to the pool only after the copy
+        inflight.append((landed, results[i], n))
         k += 1
-        if len(inflight) > depth:
-            yield retire()
+        while inflight and (len(inflight) > depth or inflight[0][0].query()):
+            yield harvest()
     while inflight:
-        yield retire()
+        yield harvest()
     compute.wait_stream(h2d)                       # the slots return to the current stream's pool
 
 

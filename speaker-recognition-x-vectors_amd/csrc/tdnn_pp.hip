@@ -116,6 +116,19 @@ __device__ unsigned long long g_pp_diag[2 * 512 * 32];   // [pooling variant][bl
         SB();                                   \
     }
 #define PP_WAIT_VM(n_) asm volatile("s_waitcnt vmcnt(" #n_ ")" ::: "memory")
+// counted wait whose count is only known at run time (it depends on the next tile's height): one of the few
+// values the request schedule can produce; anything else waits for everything (stricter, never wrong)
+#define PP_WAIT_VM_RT(n_)                                        \
+    {                                                            \
+        const int nn_ = (n_);                                    \
+        if (nn_ == 10) { PP_WAIT_VM(10); }                       \
+        else if (nn_ == 9) { PP_WAIT_VM(9); }                    \
+        else if (nn_ == 8) { PP_WAIT_VM(8); }                    \
+        else if (nn_ == 7) { PP_WAIT_VM(7); }                    \
+        else if (nn_ == 2) { PP_WAIT_VM(2); }                    \
+        else if (nn_ == 1) { PP_WAIT_VM(1); }                    \
+        else { PP_WAIT_VM(0); }                                  \
+    }
 #define PP_BARRIER() \
     {                \
         SB();        \
@@ -140,15 +153,21 @@ __device__ __forceinline__ int64_t sload_i64(const int64_t* p) {
     return v;
 }
 
+// activation source of one tile: descriptor at its first row + this lane's byte offsets of the wave's A piece of
+// acc rows 0..3
+struct Rows {
+    i32x4 xrsrc;
+    int av0, av1, av2, av3;
+};
+
 struct Stream {
-    i32x4 xrsrc, wrsrc;
-    int av0, av1, av2, av3;     // per-lane source byte offsets of this wave's A piece of acc rows 0..3
+    i32x4 wrsrc;
+    Rows cur;                   // tile the requests are for
     int wv0;                    // and of its first W piece; the others are 64 channel rows (w64 bytes, scalar) apart
     int w64;
     unsigned lds_a, lds_w;      // LDS byte address (buffer 0) of this wave's A piece of acc row 0 / its first W piece
     int row_in_group;           // this lane's row within its group's acc row 0 (A pieces), and the byte offset of
     int a_chunk;                // the (swizzled) 16-byte chunk it fetches within a 128-byte K-tile slab
-    int pending_stores;         // stores the previous tile's epilogue issued after this tile's first K-tiles (-1: unknown)
     int u_tile;                 // utterance holding the stream tile's first row, and where the next one starts
     int64_t off_next;
 };
@@ -158,7 +177,7 @@ struct Stream {
 // boundaries inside the tile are walked with block-uniform values, each lane counts the ones its
 // rows have passed)
 template <bool RAGGED>
-__device__ __forceinline__ void set_rows(const TdnnArgs& a, const Tile& t, int grp, Stream& st) {
+__device__ __forceinline__ void set_rows(const TdnnArgs& a, const Tile& t, int grp, Stream& st, Rows& out) {
     const int n_last = a.out_map.n_utts - 1;
     const int64_t t_out = a.out_map.fixed_T - a.out_map.cum;
     auto next_off = [&](int u) -> int64_t {
@@ -185,16 +204,16 @@ __device__ __forceinline__ void set_rows(const TdnnArgs& a, const Tile& t, int g
     }
     const int rb = a.ldx * 2;
     const int base = rl * rb + st.a_chunk;
-    st.av0 = base + (st.u_tile + c0) * a.span * rb;
-    st.av1 = base + 32 * rb + (st.u_tile + c1) * a.span * rb;
-    st.av2 = base + 64 * rb + (st.u_tile + c2) * a.span * rb;
-    st.av3 = base + 96 * rb + (st.u_tile + c3) * a.span * rb;
-    st.xrsrc = make_srd(static_cast<const char*>(a.X) + t.m0 * (int64_t)a.ldx * 2);
+    out.av0 = base + (st.u_tile + c0) * a.span * rb;
+    out.av1 = base + 32 * rb + (st.u_tile + c1) * a.span * rb;
+    out.av2 = base + 64 * rb + (st.u_tile + c2) * a.span * rb;
+    out.av3 = base + 96 * rb + (st.u_tile + c3) * a.span * rb;
+    out.xrsrc = make_srd(static_cast<const char*>(a.X) + t.m0 * (int64_t)a.ldx * 2);
 }
 
-__device__ __forceinline__ void set_rows(const TdnnArgs& a, const Tile& t, int grp, Stream& st) {
-    if (a.out_map.offsets == nullptr) set_rows<false>(a, t, grp, st);
-    else set_rows<true>(a, t, grp, st);
+__device__ __forceinline__ void set_rows(const TdnnArgs& a, const Tile& t, int grp, Stream& st, Rows& out) {
+    if (a.out_map.offsets == nullptr) set_rows<false>(a, t, grp, st, out);
+    else set_rows<true>(a, t, grp, st, out);
 }
 
 // Scalar source offset of the activation K-tiles, stepped one K-tile at a time (taps innermost:
@@ -225,13 +244,13 @@ __device__ __forceinline__ void kstep(const TdnnArgs& a, KPos& k) {
     }
 #define PP_ISSUE_A01(b_, so_)                                                       \
     {                                                                               \
-        dma16(st.xrsrc, st.lds_a + (b_) * kBufBytes, st.av0, so_);                  \
-        dma16(st.xrsrc, st.lds_a + (b_) * kBufBytes + kAccRowB, st.av1, so_);       \
+        dma16(st.cur.xrsrc, st.lds_a + (b_) * kBufBytes, st.cur.av0, so_);                  \
+        dma16(st.cur.xrsrc, st.lds_a + (b_) * kBufBytes + kAccRowB, st.cur.av1, so_);       \
     }
 #define PP_ISSUE_A23(MR_, b_, so_)                                                  \
     {                                                                               \
-        dma16(st.xrsrc, st.lds_a + (b_) * kBufBytes + 2 * kAccRowB, st.av2, so_);   \
-        if ((MR_) > 3) dma16(st.xrsrc, st.lds_a + (b_) * kBufBytes + 3 * kAccRowB, st.av3, so_); \
+        dma16(st.cur.xrsrc, st.lds_a + (b_) * kBufBytes + 2 * kAccRowB, st.cur.av2, so_);   \
+        if ((MR_) > 3) dma16(st.cur.xrsrc, st.lds_a + (b_) * kBufBytes + 3 * kAccRowB, st.cur.av3, so_); \
     }
 
 // first K-tiles of a tile: part 1 = all of K-tile 0; part 2 = all of K-tile 1, in the K loop's request order
@@ -294,8 +313,11 @@ struct Lane {
 // one fragment read: acc row i_ (= fragment set i_), k-step s_, from buffer b_
 #define PP_RA(i_, s_, b_) if constexpr (!PP_KNOCK_RDA) PP_RD(af##i_##_##s_, ln.a_rd + (b_) * kBufBytes + (i_) * kAccRowB + ln.k##s_)
 
-// One K-tile held in LDS buffer b_ (odd_ = its parity).  `last` = one of the tile's last two K-tiles
-// (nothing left to request two K-tiles ahead); k2.so = activation source offset of K-tile q+2.
+// One K-tile held in LDS buffer b_ (odd_ = its parity).  k2.so / wq = activation source offset and index of
+// the K-tile requested now, two K-tiles ahead; mr_req = height of the tile it belongs to.  The request stream
+// does not stop at the end of a tile: in a tile's last two K-tiles ("last") the requests are the NEXT tile's
+// K-tiles 0 and 1 (the stream state was switched to that tile just before), so a tile starts with its first
+// K-tiles in LDS and its first fragments in registers.  Only a block's last tile requests nothing there.
 //   load 0:  read the 8 W fragments; request acc rows 0,1 of K-tile q+2
 //   mfma 0:  MR=4: acc rows 0,1 (16 MFMAs); MR=3: acc rows 0,1, k-steps 0-2 (12) -- with the fragment reads of
 //            acc rows 2,(3) behind its first MFMAs
@@ -305,22 +327,25 @@ struct Lane {
 // The two segments of a wave are equally long, so the SIMD partner's load segments have the same time to
 // hide in.  Activation fragments are never read in a load segment, and never two reads behind one MFMA.
 // Every segment ends with lgkmcnt(0) before its barrier (a slot may be refilled in any later segment).
-// Counted vmcnt at the end of a load segment (request order per wave: [rows 0,1] | [W, rows 2,3] | ...):
-//   load 0 must have acc rows 2,3 of K-tile q   (requested three load segments ago): MR+6 younger pieces
-//   load 1 must have W of K-tile q+1 (two load segments ago) and rows 0,1 of q+1 (three): 2*MR+2 younger
-// -- never a drain; at the tail of a tile the counts shrink with the requests that are no longer made.
+// Counted vmcnt at the end of a load segment (request order per wave: [rows 0,1] | [W, rows 2,3] | ...; m = this
+// tile's MR, m' = mr_req, equal except in the last two K-tiles):
+//   load 0 must have acc rows 2,3 of K-tile q  (requested three load segments ago): 2 + (m'+2) + 2 younger
+//   load 1 must have W of K-tile q+1 (two load segments ago) and rows 0,1 of q+1 (three): (m1-2) + 2 + (m'+2)
+//          younger, m1 = height of the tile K-tile q+1 belongs to
+// -- never a drain.  (The epilogue's stores sit in the same queue: the first waits of the next tile then
+// wait for a few entries more than they need to, which have long completed.)
 #define PP_KTILE(b_, odd_)                                                          \
     {                                                                               \
         SB();                                                                       \
         PP_READ_W(b_)                                                               \
         SB();                                                                       \
-        if (!last && !PP_KNOCK_DMA) PP_ISSUE_A01(b_, k2.so)                         \
+        if (req && !PP_KNOCK_DMA) PP_ISSUE_A01(b_, k2.so)                           \
         SB();                                                                       \
         PP_WAIT_LGKM();                                                             \
         PP_STAMP(0)                                                                 \
         if (!last) { if (MR == 4) { PP_WAIT_VM(10); } else { PP_WAIT_VM(9); } }     \
-        else if (!(odd_)) { if (MR == 4) { PP_WAIT_VM(8); } else { PP_WAIT_VM(7); } } \
-        else { PP_WAIT_VM(0); }                                                     \
+        else if (!(odd_)) { PP_WAIT_VM_RT(req ? MR + 6 : MR + 4) }                  \
+        else { PP_WAIT_VM_RT(req ? mr_req + 6 : 0) }                                \
         PP_STAMP(1)                                                                 \
         PP_BARRIER()                                                                \
         PP_STAMP(2)                                                                 \
@@ -339,21 +364,21 @@ struct Lane {
         PP_STAMP(3)                                                                 \
         PP_BARRIER()                                                                \
         PP_STAMP(4)                                                                 \
-        if (!last && !PP_KNOCK_DMA) {                                               \
-            PP_ISSUE_W(b_, q + 2 + (odd_ ? 1 : 0))                                  \
-            PP_ISSUE_A23(MR, b_, k2.so)                                             \
+        if (req && !PP_KNOCK_DMA) {                                                 \
+            PP_ISSUE_W(b_, wq)                                                      \
+            PP_ISSUE_A23(mr_req, b_, k2.so)                                         \
         }                                                                           \
         SB();                                                                       \
         PP_STAMP(6)                                                                 \
         if (!last) { if (MR == 4) { PP_WAIT_VM(10); } else { PP_WAIT_VM(8); } }     \
-        else if (!(odd_)) { if (MR == 4) { PP_WAIT_VM(2); } else { PP_WAIT_VM(1); } } \
-        else { PP_WAIT_VM(0); }                                                     \
+        else if (!(odd_)) { PP_WAIT_VM_RT(req ? MR + mr_req + 2 : MR - 2) }         \
+        else { PP_WAIT_VM_RT(req ? 2 * mr_req + 2 : 0) }                            \
         PP_STAMP(7)                                                                 \
         PP_BARRIER()                                                                \
         PP_STAMP(8)                                                                 \
         __builtin_amdgcn_s_setprio(1);                                              \
         if constexpr (MR == 3) { PP_MF4(0, 1, 3) SB(); }                            \
-        /* (after the tile's last K-tile these reads fetch stale bytes that nobody uses: cheaper than a branch */ \
+        /* (after a block's last K-tile these reads fetch stale bytes that nobody uses: cheaper than a branch */ \
         /*  around the MFMAs, which made hipcc keep two register assignments alive and spill) */ \
         PP_M1(2, 0, 0) PP_RA(0, 0, (b_) ^ 1) SB(); PP_M1(2, 1, 0) PP_RA(0, 1, (b_) ^ 1) SB(); \
         PP_M1(2, 0, 1) PP_RA(0, 2, (b_) ^ 1) SB(); PP_M1(2, 1, 1) PP_RA(0, 3, (b_) ^ 1) SB(); \
@@ -368,6 +393,7 @@ struct Lane {
         PP_BARRIER()                                                                \
         PP_STAMP(10)                                                                \
         kstep(a, k2);                                                               \
+        ++wq;                                                                       \
     }
 
 // ReLU + folded BatchNorm on one accumulator whose REGISTERS are channels (store variant): element e =
@@ -490,9 +516,13 @@ __device__ __forceinline__ bool pool_raw_pair(const TdnnArgs& a, const f32x16& v
 
 // One tile: K loop, request of the next tile's first K-tiles, epilogue.
 template <int MR, bool POOL>
-__device__ __forceinline__ void process_tile(const TdnnArgs& a, char* smem, Stream& st, const Lane& ln, const Tile& t,
-                                             const Tile& nxt, bool has_next, int n0, int nk, PoolCur& pc, float bi0,
-                                             float bi1) {
+__device__ __forceinline__ void process_tile(const TdnnArgs& a, char* smem, Stream& st, const Lane& ln,
+                                             const Tile& t, const Tile& nxt, bool has_next, bool first, int n0, int nk,
+                                             PoolCur& pc, float bi0, float bi1) {
+    // source rows of the NEXT tile (its first K-tiles are requested during this tile's last two): worked out
+    // here, before the accumulators exist, and parked in four registers
+    Rows rows_next = st.cur;
+    if (has_next) set_rows(a, nxt, ln.grp, st, rows_next);
     // the accumulators start at the bias: of their lane's channel (pooling variant: channel on the lane), or of
     // each register's channel (store variant: 16 channels per lane and column, from the LDS copy)
     f32x16 acc00, acc01, acc10, acc11, acc20, acc21, acc30, acc31;
@@ -531,48 +561,53 @@ __device__ __forceinline__ void process_tile(const TdnnArgs& a, char* smem, Stre
         af2_0 = af2_1 = af2_2 = af2_3 = af3_0 = af3_1 = af3_2 = af3_3 = z;
     }
 #endif
-    // K-tile 0 complete: its pieces are older than the MR+4 of K-tile 1 and than the stores the previous
-    // tile's epilogue issued behind them -- count those instead of waiting for them (unknown count: wait)
-    {
-        const int ps = st.pending_stores;
-        if (ps == 16) { if (MR == 4) { PP_WAIT_VM(24); } else { PP_WAIT_VM(23); } }
-        else if (ps == 12) { if (MR == 4) { PP_WAIT_VM(20); } else { PP_WAIT_VM(19); } }
-        else if (ps == 0) { if (MR == 4) { PP_WAIT_VM(8); } else { PP_WAIT_VM(7); } }
-        else { PP_WAIT_VM(0); }
+    // A block's first tile waits for its first K-tile (requested by the kernel prologue; its pieces are older
+    // than the MR+4 of K-tile 1); later tiles find it in LDS, confirmed by the previous tile's last K-tiles.
+    if (first) {
+        if (MR == 4) { PP_WAIT_VM(8); } else { PP_WAIT_VM(7); }
+        PP_BARRIER()
     }
+    // acc rows 0,1 of K-tile 0: the only activation fragments read outside an MFMA segment (the previous tile's
+    // last MFMA segment fetched them too, but keeping them in registers across the epilogue costs it 32 VGPRs)
+    PP_RA(0, 0, 0) PP_RA(0, 1, 0) PP_RA(0, 2, 0) PP_RA(0, 3, 0)
+    PP_RA(1, 0, 0) PP_RA(1, 1, 0) PP_RA(1, 2, 0) PP_RA(1, 3, 0)
+    PP_WAIT_LGKM();
+    // Their slots are the first ones the loop refills (load 0 of K-tile 0 requests K-tile 2 into them), and the
+    // waves of a group leave the epilogue at different times: every wave must have read them before any wave
+    // may request.  (Deferring that one request instead costs a branch in the loop, and with it hipcc's
+    // register assignment: 160 spilled registers.)
     PP_BARRIER()
     if (ln.grp == 1) PP_BARRIER()          // ping-pong: the second group runs one barrier behind
 #ifdef XVEC_DIAG
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dprev)::"memory");
     dsum[12] += dprev - dstart;            // head wait
 #endif
-    // acc rows 0,1 of K-tile 0: the only activation fragments read outside an MFMA segment
-    PP_RA(0, 0, 0) PP_RA(0, 1, 0) PP_RA(0, 2, 0) PP_RA(0, 3, 0)
-    PP_RA(1, 0, 0) PP_RA(1, 1, 0) PP_RA(1, 2, 0) PP_RA(1, 3, 0)
-    PP_WAIT_LGKM();                         // (their slots are the first ones the loop refills)
-    KPos k2 = {0, 0};                       // K-tile q+2
+    KPos k2 = {0, 0};                       // K-tile requested now (two ahead of the one computed), its W index,
+    kstep(a, k2);                           // the height of its tile, and whether there is anything to request
     kstep(a, k2);
-    kstep(a, k2);
+    int wq = 2;
+    int mr_req = MR;
+    bool req = true;
     for (int q = 0; q < nk; q += 2) {
         const bool last = q + 2 >= nk;
+        if (last) {                         // from here on the requests are the next tile's K-tiles 0 and 1
+            req = has_next;                 // (a peeled copy of the last pair made hipcc spill ~250 registers)
+            if (has_next) {
+                st.cur = rows_next;
+                mr_req = nxt.mr;
+                k2.tap = 0;
+                k2.so = 0;
+                wq = 0;
+            }
+        }
         PP_KTILE(0, false)
         PP_KTILE(1, true)
     }
     if (ln.grp == 0) PP_BARRIER()
     PP_STAMP(13)                            // tail barrier
-    // every wave is past its last LDS read: both buffers are free.  The next tile's first two K-tiles are
-    // requested before the epilogue (the DMA flies under it); the epilogue's stores are then the youngest
-    // entries of the vector-memory queue, and the next tile's first wait counts them (st.pending_stores,
-    // -1 = unknown: wait for everything) instead of waiting for them.
-    if (has_next) {
-        set_rows(a, nxt, ln.grp, st);
-        issue_head1(a, st, nxt.mr);
-        issue_head2(a, st, nxt.mr);
-    }
-    PP_STAMP(5)                             // rows + first K-tiles of the next tile
+    PP_STAMP(5)
 
     const int64_t row0 = t.m0 + ln.grp * 32 * MR;
-    int n_st = 0;
     if constexpr (PP_KNOCK_EPI) {
         asm volatile("" ::"v"(acc00), "v"(acc01), "v"(acc10), "v"(acc11), "v"(acc20), "v"(acc21), "v"(acc30), "v"(acc31));
     } else if constexpr (!POOL) {
@@ -582,7 +617,6 @@ __device__ __forceinline__ void process_tile(const TdnnArgs& a, char* smem, Stre
 #define PP_STORE(i_, j_)                                                                               \
         if (MR > i_ && row0 + 32 * i_ < t.valid_end) {                                                    \
             store_acc(acc##i_##j_, sc, sh, yrsrc, y_voff, (ln.grp * 32 * MR + 32 * i_) * a.ldy * 2 + 64 * j_); \
-            n_st += 2;                                                                                    \
         }
         {
             float4 sc[4], sh[4];
@@ -605,11 +639,9 @@ __device__ __forceinline__ void process_tile(const TdnnArgs& a, char* smem, Stre
 #undef PP_STORE
     } else {
         const int col0 = n0 + ln.wc * 64 + ln.r;
-        bool regular = true;
 #define PP_POOL(RG_, i_)                                                                               \
         if (MR > i_ && row0 + 32 * i_ < t.valid_end) {                                                    \
-            regular &= pool_raw_pair<RG_>(a, acc##i_##0, acc##i_##1, row0 + 32 * i_, ln.h, col0, pc);     \
-            n_st += 4;                                                                                    \
+            pool_raw_pair<RG_>(a, acc##i_##0, acc##i_##1, row0 + 32 * i_, ln.h, col0, pc);                \
         }
         if (a.out_map.offsets == nullptr) {
             PP_POOL(false, 0) PP_POOL(false, 1) PP_POOL(false, 2) PP_POOL(false, 3)
@@ -617,9 +649,7 @@ __device__ __forceinline__ void process_tile(const TdnnArgs& a, char* smem, Stre
             PP_POOL(true, 0) PP_POOL(true, 1) PP_POOL(true, 2) PP_POOL(true, 3)
         }
 #undef PP_POOL
-        if (!regular) n_st = -1;
     }
-    st.pending_stores = n_st;
 #ifdef XVEC_DIAG
     {
         unsigned long long dend;
@@ -693,10 +723,10 @@ __global__ __launch_bounds__(kThreads, 2) void tdnn_pp_kernel(const TdnnArgs a) 
         st.wv0 = wr * kb + w_chunk;
         st.w64 = 64 * kb;
         st.wrsrc = make_srd(static_cast<const char*>(a.W) + (int64_t)n0 * kb);
-        st.av0 = st.av1 = st.av2 = st.av3 = 0;
+        st.cur.av0 = st.cur.av1 = st.cur.av2 = st.cur.av3 = 0;
         st.u_tile = __builtin_amdgcn_readfirstlane(utt_of_row(a.out_map, u_begin * 64));
         st.off_next = row_off(a.out_map, st.u_tile + 1);
-        st.xrsrc = st.wrsrc;
+        st.cur.xrsrc = st.wrsrc;
         PoolCur pc;
         pc.u = 0;
         pc.end = 0;
@@ -719,19 +749,18 @@ __global__ __launch_bounds__(kThreads, 2) void tdnn_pp_kernel(const TdnnArgs a) 
         };
         Tile cur = tile_at(0, u_begin * 64);
         if (POOL) pc = pool_cursor(a, cur.m0 + ln.grp * 32 * cur.mr);
-        set_rows(a, cur, ln.grp, st);
+        set_rows(a, cur, ln.grp, st, st.cur);
         __syncthreads();                                   // constants visible; nobody reads LDS buffers yet
         issue_head1(a, st, cur.mr);
         issue_head2(a, st, cur.mr);
-        st.pending_stores = 0;
         for (int idx = 0; idx < nt; ++idx) {
             const bool has_next = idx + 1 < nt;
             Tile nxt = cur;
             if (has_next) nxt = tile_at(idx + 1, cur.m0 + 64 * cur.mr);
             if (cur.mr == 4)
-                process_tile<4, POOL>(a, smem, st, ln, cur, nxt, has_next, n0, nk, pc, bi0, bi1);
+                process_tile<4, POOL>(a, smem, st, ln, cur, nxt, has_next, idx == 0, n0, nk, pc, bi0, bi1);
             else
-                process_tile<3, POOL>(a, smem, st, ln, cur, nxt, has_next, n0, nk, pc, bi0, bi1);
+                process_tile<3, POOL>(a, smem, st, ln, cur, nxt, has_next, idx == 0, n0, nk, pc, bi0, bi1);
             cur = nxt;
         }
     }

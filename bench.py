@@ -319,7 +319,11 @@ def main():
         bf = args.dtype in ("bf16", "bf16x3")
         # bf16x3 spends three bf16 MFMAs per algorithmic product: its roof is a third of the bf16 peak
         peak = {"fp32": FP32_MFMA_PEAK, "bf16": BF16_MFMA_PEAK, "bf16x3": BF16_MFMA_PEAK / 3}[args.dtype]
-        dom_kernel = ("xvec::tdnn_kernel<false,false,true,true,true> (layers 2-4, bf16 MFMA"
+        # bf16 at this batch size runs the 256-channel ping-pong mapping (csrc/tdnn_pp.hip); smaller batches and
+        # bf16x3 the 128x128 kernel (csrc/tdnn_layer.hip)
+        pp16 = args.dtype == "bf16" and B * (T - 14) >= 3 * 64 * 128
+        dom_kernel = ("xvec::pp::tdnn_pp_kernel<false> (layers 2-4, bf16 MFMA, LDS-DMA operands)" if pp16 else
+                      "xvec::tdnn_kernel<false,false,true,true,true> (layers 2-4, bf16 MFMA"
                       + (", three products per k-step)" if args.dtype == "bf16x3" else ")") if bf else
                       "xvec::tdnn_kernel<false,false,true,false,false> (layers 2-4, fp32 MFMA)")
         value = n_done / dt
@@ -329,8 +333,9 @@ def main():
         traffic, traffic_src = None, None
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+            tj = tj[args.dtype]                             # one section per arithmetic (bf16x3: no PMC pass yet)
             key = {"fp32": "tdnn_kernel<false, false, true, false, false",
-                   "bf16": "tdnn_kernel<false, false, true, true, true"}[args.dtype]   # bf16x3: no PMC pass yet
+                   "bf16": "pp::tdnn_pp_kernel<false" if pp16 else "tdnn_kernel<false, false, true, true, true"}[args.dtype]
             key = next(k for k in tj if k.startswith(key) and not k.rstrip(">").endswith(", true, true, true, true"))
             traffic, traffic_src = tj[key]["hbm_bytes_per_launch"], tj["source"]
         except (OSError, KeyError, ValueError, StopIteration):

@@ -78,7 +78,7 @@ def v_h2d_only():
     compute.wait_stream(h2d)
 
 
-def _pipeline(ring, side_h2d, depth=2):
+def _pipeline(ring, side_h2d, depth=2, clone=False, stats=None):
     compute = torch.cuda.current_stream(dev)
     h2d, d2h = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
     slots = [torch.empty_like(x_dev) for _ in range(depth + 1)]
@@ -88,7 +88,21 @@ def _pipeline(ring, side_h2d, depth=2):
 
     def harvest():
         ev, buf = inflight.pop(0)
+        t0 = time.perf_counter()
         ev.synchronize()
+        t1 = time.perf_counter()
+        if clone == "numpy":
+            c = torch.from_numpy(buf.numpy().copy())
+            t2 = time.perf_counter()
+            if stats is not None:
+                stats.append((t1 - t0, t2 - t1))
+            return float(c[0, 0]) + float(c[B - 1, 511])
+        if clone:
+            c = buf.clone()
+            t2 = time.perf_counter()
+            if stats is not None:
+                stats.append((t1 - t0, t2 - t1))
+            return float(c[0, 0]) + float(c[B - 1, 511])
         return float(buf[0, 0]) + float(buf[B - 1, 511])
 
     for k in range(N):
@@ -131,7 +145,12 @@ variants = {
     "d2h_pin": lambda: _pipeline(ring_pin, False), "d2h_reg": lambda: _pipeline(ring_reg, False),
     "both_pin": lambda: _pipeline(ring_pin, True), "both_reg": lambda: _pipeline(ring_reg, True),
     "both_reg_d4": lambda: _pipeline(ring_reg, True, depth=3),
+    "both_pin_clone": lambda: _pipeline(ring_pin, True, depth=3, clone=True, stats=clone_stats),
+    "both_reg_clone": lambda: _pipeline(ring_reg, True, depth=3, clone=True, stats=clone_stats2),
+    "both_pin_npcopy": lambda: _pipeline(ring_pin, True, depth=3, clone="numpy", stats=clone_stats3),
 }
+clone_stats3 = []
+clone_stats, clone_stats2 = [], []
 if hasattr(xa.extract, "stream_x_vectors_r1"):
     variants["r1"] = v_r1
 variants["shipped"] = lambda: sum(float(h[0, 0]) for h in xa.extract.stream_x_vectors(m, (x_host for _ in range(N))))
@@ -156,6 +175,10 @@ for name, v in times.items():
     print(f"{name:12s} ms/batch median {v[len(v) // 2]:.3f}  min {v[0]:.3f}  max {v[-1]:.3f}   -> {B / v[len(v) // 2] * 1e3:9.0f} emb/s",
           flush=True)
 
+print("torch threads", torch.get_num_threads(), "cpu_count", os.cpu_count())
+for nm, st in (("pin", clone_stats), ("reg", clone_stats2), ("pin numpy copy", clone_stats3)):
+    if st:
+        print(f"{nm}: event wait mean {1e3 * sum(a for a, _ in st) / len(st):.3f} ms, clone mean {1e3 * sum(b for _, b in st) / len(st):.3f} ms, clone max {1e3 * max(b for _, b in st):.3f} ms")
 # CPU read cost of the two kinds of result buffer
 for nm, ring in (("pinned", ring_pin), ("registered", ring_reg)):
     t0 = time.perf_counter()

@@ -95,10 +95,30 @@ hipError_t launch_pack_tdnn_bf16(const float* W, const TdnnGeom& geo, void* Wf16
     return hipGetLastError();
 }
 
-// row-major bf16 [n_pad][k_pad] (64-element chunks, taps innermost): both operands of tdnn_pp.hip reach
-// LDS by DMA in 128-byte row slabs, so its weights keep plain rows
+// bf16 weights for tdnn_pp.hip, K-TILE major: [256-channel column block][K-tile of 64][256 channels][64 k]
+// (K order as everywhere: 64-element chunks, taps innermost).  Both operands of that kernel reach LDS by
+// DMA in 128-byte row slabs; a K-tile of a column block is then one contiguous 32 KiB, so the 256 CUs
+// that fetch the same tile at the same time spread over all L2 channels (128-byte slabs of plain rows,
+// 1-3 KiB apart, fall on two of them).
+__global__ void pack_tdnn_weight_ktile_kernel(const float* __restrict__ W, TdnnGeom g, __bf16* __restrict__ Wt) {
+    const int64_t total = (int64_t)g.n_pad * g.k_pad;
+    const int nk = g.k_pad / 64;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int w = (int)(i & 63), r = (int)((i >> 6) & 255);
+        const int64_t t = i >> 14;                       // (column block, K-tile)
+        const int cb = (int)(t / nk), q = (int)(t % nk);
+        const int n = cb * 256 + r, kd = tap_major_k(g, q * 64 + w);
+        const int tap = kd / g.tap_stride_src, c = kd % g.tap_stride_src;
+        float v = 0.f;
+        if (n < g.cout && tap < g.src_taps && c < g.src_cin)
+            v = W[(int64_t)n * (g.src_taps * g.src_cin) + tap * g.src_cin + c];
+        Wt[i] = (__bf16)v;
+    }
+}
 hipError_t launch_pack_tdnn_rows_bf16(const float* W, const TdnnGeom& geo, void* Wr16, hipStream_t s) {
-    pack_tdnn_weight_kernel<__bf16><<<1024, 256, 0, s>>>(W, geo, static_cast<__bf16*>(Wr16));
+    if (geo.n_pad % 256 != 0) return hipSuccess;        // tdnn_pp.hip is not used for such a layer
+    pack_tdnn_weight_ktile_kernel<<<1024, 256, 0, s>>>(W, geo, static_cast<__bf16*>(Wr16));
     return hipGetLastError();
 }
 

@@ -236,7 +236,7 @@ __device__ __forceinline__ void kstep(const TdnnArgs& a, KPos& k) {
 // W: the wave's four pieces (channel rows 8*(wave + 8t) ..+7); A01 / A23: its piece of acc rows 0,1 / 2,(3)
 #define PP_ISSUE_W(b_, q_)                                                          \
     {                                                                               \
-        const int so_ = (q_) * 128;                                                 \
+        const int so_ = (q_) * kWBytes;              /* K-tile major weights: 32 KiB per K-tile */ \
         dma16(st.wrsrc, st.lds_w + (b_) * kBufBytes, st.wv0, so_);                  \
         dma16(st.wrsrc, st.lds_w + (b_) * kBufBytes + 8 * 1024, st.wv0, so_ + st.w64);       \
         dma16(st.wrsrc, st.lds_w + (b_) * kBufBytes + 16 * 1024, st.wv0, so_ + 2 * st.w64);  \
@@ -719,10 +719,9 @@ __global__ __launch_bounds__(kThreads, 2) void tdnn_pp_kernel(const TdnnArgs a) 
         const int wr = ln.wave * 8 + prow;                                // W: channel row of piece t = wr + 64*t
         const int w_chunk = (ppos ^ ((wr >> 1) & 7)) * 16;                // ((wr + 64t) >> 1) & 7 is the same for every t
         st.lds_w = (unsigned)(unsigned long long)(lds_ptr)(smem) + kABytes + ln.wave * 1024;
-        const int kb = a.k_pad * 2;
-        st.wv0 = wr * kb + w_chunk;
-        st.w64 = 64 * kb;
-        st.wrsrc = make_srd(static_cast<const char*>(a.W) + (int64_t)n0 * kb);
+        st.wv0 = wr * kRowB + w_chunk;                                    // K-tile major: rows 128 B apart
+        st.w64 = 64 * kRowB;
+        st.wrsrc = make_srd(static_cast<const char*>(a.W) + (int64_t)jcol * nk * kWBytes);
         st.cur.av0 = st.cur.av1 = st.cur.av2 = st.cur.av3 = 0;
         st.u_tile = __builtin_amdgcn_readfirstlane(utt_of_row(a.out_map, u_begin * 64));
         st.off_next = row_off(a.out_map, st.u_tile + 1);

@@ -123,10 +123,10 @@ enum class TdnnVariant {
 };
 hipError_t launch_tdnn(const TdnnArgs& a, TdnnVariant v, hipStream_t s);
 // Large-batch bf16 mapping (tdnn_pp.hip): 256-channel columns, 64-frame units.  Reads TdnnArgs with
-//   W = row-major bf16 [n_pad][k_pad] (K order as the fp32 packing, 64-element chunks), n_tiles = n_pad / 256,
+//   W = K-tile major bf16 [n_pad/256][k_pad/64][256][64] (K order as the fp32 packing, 64-element chunks), n_tiles = n_pad / 256,
 //   groups_total = ceil(rows / 64) units, blocks_per_col ranges per column (>= 3 units each for full speed).
 hipError_t launch_tdnn_pp(const TdnnArgs& a, bool pool, hipStream_t s);
-// row-major bf16 copy of the packed weights for it
+// K-tile major bf16 copy of the packed weights for it
 hipError_t launch_pack_tdnn_rows_bf16(const float* W, const TdnnGeom& geo, void* Wr16, hipStream_t s);
 
 struct PoolArgs {

@@ -143,9 +143,13 @@ def stream_x_vectors(model, host_batches: Iterable[torch.Tensor], device=None, d
         stream (device input slots: a ring of depth+1 buffers per shape, allocated once -- an allocation
         inside the loop could reach hipMalloc, which synchronises the device);
       * the result of batch k is copied device->host on a third stream, enqueued right behind the
-        batch's `done` event into a ring of pinned result buffers (non-blocking), and handed out
+        batch's `done` event into a ring of page-locked result buffers (non-blocking), and handed out
         `depth` batches later -- or earlier, as soon as its copy is known to have landed
-        (event.query(), no wait) -- as an ordinary (pageable) clone, so the pinned slot can be reused.
+        (event.query(), no wait) -- as an ordinary (pageable) clone, so the slot can be reused.
+        The ring lives in torch's caching pinned allocator, so only the first call pays for
+        hipHostMalloc.  (Locking ordinary memory with hipHostRegister per call instead cost ~90 ms
+        per buffer -- 13 ms per batch over a 30-batch job; CPU reads of either kind of page-locked
+        memory take 0.03 ms per 512 KiB on the boxes measured, profiles/diag/stream_probe3.py.)
     Round 1 fetched every result with a host-blocking `.cpu()` behind an event wait; on the driver's
     box that pipeline was slower than the plain loop (BENCH_r01: 78.0 k vs 80.2 k embeddings/s against
     90.1 k resident), here it is not (profiles/diag/stream_probe3.py) -- host wake-up latencies differ
@@ -162,52 +166,61 @@ def stream_x_vectors(model, host_batches: Iterable[torch.Tensor], device=None, d
     n_ring = depth + 1
     slots = [None] * n_ring      # device inputs
     consumed = [None] * n_ring   # event: the batch that read the slot has been computed
-    results = [None] * n_ring    # pinned host result buffers [rows, D]
-    inflight = []                # (landed event, pinned buffer, rows)
+    results = [None] * n_ring    # page-locked host result buffers [rows, D]
+    inflight = []                # (landed event, host buffer, rows)
+
+    def locked(rows, D, dtype):
+        return torch.empty((max(rows, 1), D), dtype=dtype, pin_memory=True)
 
     def harvest():
         ev, buf, n = inflight.pop(0)
         ev.synchronize()                           # returns at once when query() was already true
-        return buf[:n].clone()
+        # a plain single-threaded memcpy: tensor.clone() goes through torch's intra-op thread pool, and waking
+        # that pool (one thread per visible CPU -- 256 on the GPU box, under a 16-CPU quota) next to the
+        # runtime's polling threads took 9-12 ms per 512 KiB clone, 100 ms at worst (stream_probe3.py)
+        return torch.from_numpy(buf[:n].numpy().copy())
 
-    k = 0
-    for xb in host_batches:
-        if xb.device.type != "cpu":
-            raise ValueError("stream_x_vectors: expected host tensors (device batches: call extract_x_vec directly)")
-        i = k % n_ring
-        fresh = slots[i] is None or slots[i].shape != xb.shape or slots[i].dtype != xb.dtype
-        if fresh:
-            slots[i] = None
-            slots[i] = torch.empty(xb.shape, dtype=xb.dtype, device=dev)   # from the current stream's pool
-        with torch.cuda.stream(h2d):
+    def pipeline():
+        k = 0
+        for xb in host_batches:
+            if xb.device.type != "cpu":
+                raise ValueError("stream_x_vectors: expected host tensors (device batches: call extract_x_vec directly)")
+            i = k % n_ring
+            fresh = slots[i] is None or slots[i].shape != xb.shape or slots[i].dtype != xb.dtype
             if fresh:
-                h2d.wait_stream(compute)           # whatever used that memory before is done
-            elif consumed[i] is not None:
-                h2d.wait_event(consumed[i])        # the slot's previous batch has been read
-            slots[i].copy_(xb, non_blocking=True)
-            arrived = torch.cuda.Event()
-            arrived.record(h2d)
-        compute.wait_event(arrived)
-        out = model.extract_x_vec(slots[i])        # enqueued on the current stream
-        done = torch.cuda.Event()
-        done.record(compute)
-        consumed[i] = done
-        n, D = out.shape
-        if results[i] is None or results[i].shape[0] < n or results[i].shape[1] != D:
-            results[i] = torch.empty((max(n, 1), D), dtype=out.dtype).pin_memory()
-        with torch.cuda.stream(d2h):               # not the compute stream: there the copy would queue
-            d2h.wait_event(done)                   # behind the younger batches already enqueued
-            results[i][:n].copy_(out, non_blocking=True)
-            landed = torch.cuda.Event()
-            landed.record(d2h)
-        out.record_stream(d2h)                     # its memory returns to the pool only after the copy
-        inflight.append((landed, results[i], n))
-        k += 1
-        while inflight and (len(inflight) > depth or inflight[0][0].query()):
+                slots[i] = None
+                slots[i] = torch.empty(xb.shape, dtype=xb.dtype, device=dev)   # from the current stream's pool
+            with torch.cuda.stream(h2d):
+                if fresh:
+                    h2d.wait_stream(compute)           # whatever used that memory before is done
+                elif consumed[i] is not None:
+                    h2d.wait_event(consumed[i])        # the slot's previous batch has been read
+                slots[i].copy_(xb, non_blocking=True)
+                arrived = torch.cuda.Event()
+                arrived.record(h2d)
+            compute.wait_event(arrived)
+            out = model.extract_x_vec(slots[i])        # enqueued on the current stream
+            done = torch.cuda.Event()
+            done.record(compute)
+            consumed[i] = done
+            n, D = out.shape
+            if results[i] is None or results[i].shape[0] < n or results[i].shape[1] != D:
+                results[i] = locked(n, D, out.dtype)
+            with torch.cuda.stream(d2h):               # not the compute stream: there the copy would queue
+                d2h.wait_event(done)                   # behind the younger batches already enqueued
+                results[i][:n].copy_(out, non_blocking=True)
+                landed = torch.cuda.Event()
+                landed.record(d2h)
+            out.record_stream(d2h)                     # its memory returns to the pool only after the copy
+            inflight.append((landed, results[i], n))
+            k += 1
+            while inflight and (len(inflight) > depth or inflight[0][0].query()):
+                yield harvest()
+        while inflight:
             yield harvest()
-    while inflight:
-        yield harvest()
-    compute.wait_stream(h2d)                       # the slots return to the current stream's pool
+        compute.wait_stream(h2d)                       # the slots return to the current stream's pool
+
+    yield from pipeline()
 
 
 def extract_x_vectors(model, loader: Iterable) -> List[tuple]:

@@ -199,7 +199,9 @@ def main():
         dt_pcie = time.perf_counter() - t1
         # the product's pipelined form (extract.stream_x_vectors: next batch's H2D on a side stream)
         if lengths is None:
-            for _ in xa.extract.stream_x_vectors(model, (x_host for _ in range(3))):
+            # warm-up long enough to touch every slot of the pipeline's rings (depth + 1 device inputs and pinned
+            # result buffers: first-use hipMalloc / hipHostMalloc cost milliseconds and synchronise the device)
+            for _ in xa.extract.stream_x_vectors(model, (x_host for _ in range(8))):
                 pass
             torch.cuda.synchronize(dev)
             t2 = time.perf_counter()

@@ -30,6 +30,38 @@ __device__ __forceinline__ float add_halves(float x) {
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc_n(const void* p, int num_bytes) {
+    // uniform by construction (kernel argument + blockIdx-derived offset); readfirstlane makes
+    // that provable so hipcc emits no waterfall loop around the buffer loads
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    void* q = reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo);
+    return __builtin_amdgcn_make_buffer_rsrc(q, (short)0, __builtin_amdgcn_readfirstlane(num_bytes), 0x00020000);
+}
+
+// descriptor without a range limit (the buffers behind it are padded for every over-read)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) { return make_rsrc_n(p, 0x7fffffff); }
+
+// descriptor of base + off that ends where the buffer of `total` bytes ends: the hardware range
+// check then returns zeros for every byte past the end, with no instruction spent on it
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc_bounded(const void* base, int64_t off, int64_t total) {
+    int64_t left = total - off;
+    left = left < 0 ? 0 : (left > 0x7fffffff ? 0x7fffffff : left);
+    return make_rsrc_n(static_cast<const char*>(base) + off, (int)left);
+}
+
+// One float of a pooling partial: slot `slot` (32-row group + utterance), plane 0/1, column col -- as a buffer
+// store (scalar slot offset + one 32-bit lane offset): a plain `part[...] = v` costs a 64-bit address in
+// two VGPRs per store, in an epilogue that has none to spare.  (The buffer is < 2 GiB: make_plan.)
+// Both lane halves hold both values after add_halves: half 0 stores plane 0, half 1 plane 1, so a partial
+// is ONE store instruction of two 128-byte segments (not two half-empty ones).
+__device__ __forceinline__ void store_partial(__amdgpu_buffer_rsrc_t prs, int ld, int64_t slot, int h, int col, float v0,
+                                              float v1) {
+    const int soff = (int)(slot * 2 * ld) * 4;
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(h ? v1 : v0), prs, (col + h * ld) * 4, soff, 0);
+}
+
 // Pooling cursor of a block: the utterance that holds the first row of the next 32-row group, and
 // the compact row where it ends.  Rows only grow along a block's range, so it advances with a few
 // scalar steps per group instead of a 64-bit division / binary search each time.
@@ -38,9 +70,22 @@ struct PoolCur {
     int64_t end;
 };
 
+// Row offset of a ragged batch through the SCALAR cache.  hipcc loads `offsets[u]` with a vector load even
+// for a provably uniform u (the pointer is not known to be read-only), and the s_waitcnt vmcnt(0) it puts
+// behind that load drains every vector-memory operation the wave has in flight (the staging loads of the
+// K loop, the LDS-DMA queue of tdnn_pp.hip); the array is written by the host before the launch.
+__device__ __forceinline__ int64_t sload_i64(const int64_t* p) {
+    int64_t v;
+    asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+    return v;
+}
+
+// first compact row of utterance u; u is made provably wave-uniform so that everything derived from it
+// (64-bit row numbers, masks) lives in scalar registers
 template <bool RAGGED>
 __device__ __forceinline__ int64_t pool_first_row(const RowMap& m, int u) {
-    if (RAGGED) return m.offsets[u] - (int64_t)u * m.cum;
+    u = __builtin_amdgcn_readfirstlane(u);
+    if (RAGGED) return sload_i64(m.offsets + u) - (int64_t)u * m.cum;
     return (int64_t)u * (m.fixed_T - m.cum);
 }
 
@@ -55,34 +100,31 @@ __device__ __forceinline__ void pool_group_impl(const TdnnArgs& a, const f32x16&
                                                 float c, PoolCur& pc) {
     const int64_t grp = row_g >> 5;
     const RowMap& m = a.out_map;
+    const __amdgpu_buffer_rsrc_t prs = make_rsrc(a.pool_part);
     while (pc.end <= row_g && pc.u < m.n_utts - 1) {
-        ++pc.u;
+        pc.u = __builtin_amdgcn_readfirstlane(pc.u + 1);
         pc.end = pool_first_row<RAGGED>(m, pc.u + 1);
     }
     if (pc.end >= row_g + 32) {               // whole group inside utterance pc.u: no masks
-        f32x2 sv = {0.f, 0.f};
-#pragma unroll
-        for (int e = 0; e < 16; e += 2) sv += f32x2{v[e], v[e + 1]};
-        float s = sv.x + sv.y;
-        s = add_halves(s);
-        const float mean = s * (1.f / 32.f);
-        const f32x2 mv = {mean, mean};
-        f32x2 qv = {0.f, 0.f};
+        // one pass, shifted by c like the masked path below (c = the column's BatchNorm shift: every value is
+        // relu(.)*scale + c, so s2 - s1^2/n does not cancel), two values per instruction; a mean-then-
+        // deviations second pass kept four more registers alive in an epilogue that has none to spare
+        f32x2 p1 = {0.f, 0.f}, p2 = {0.f, 0.f};
+        const f32x2 cv = {c, c};
 #pragma unroll
         for (int e = 0; e < 16; e += 2) {
-            const f32x2 d = f32x2{v[e], v[e + 1]} - mv;
-            qv = __builtin_elementwise_fma(d, d, qv);
+            const f32x2 d = f32x2{v[e], v[e + 1]} - cv;
+            p1 += d;
+            p2 = __builtin_elementwise_fma(d, d, p2);
         }
-        float m2 = qv.x + qv.y;
-        m2 = add_halves(m2);
-        if (h == 0) {
-            float* part = a.pool_part + (grp + pc.u) * (int64_t)(2 * a.ldy);
-            part[col] = mean;
-            part[a.ldy + col] = m2;
-        }
+        const float s1 = add_halves(p1.x + p1.y), s2 = add_halves(p2.x + p2.y);
+        const float dm = s1 * (1.f / 32.f);
+        const float mean = c + dm;
+        const float m2 = fmaxf(s2 - s1 * dm, 0.f);
+        store_partial(prs, a.ldy, grp + pc.u, h, col, mean, m2);
         return;
     }
-    for (int u = pc.u; u < m.n_utts; ++u) {
+    for (int u = pc.u; u < m.n_utts; u = __builtin_amdgcn_readfirstlane(u + 1)) {
         const int64_t off = pool_first_row<RAGGED>(m, u);
         if (off >= row_g + 32) break;
         const int64_t end = pool_first_row<RAGGED>(m, u + 1);
@@ -111,11 +153,7 @@ __device__ __forceinline__ void pool_group_impl(const TdnnArgs& a, const f32x16&
         const float dm = s1 * (1.f / (float)(hi_l - lo_l));
         const float mean = c + dm;
         const float m2 = fmaxf(s2 - s1 * dm, 0.f);
-        if (h == 0) {
-            float* part = a.pool_part + (grp + u) * (int64_t)(2 * a.ldy);
-            part[col] = mean;
-            part[a.ldy + col] = m2;
-        }
+        store_partial(prs, a.ldy, grp + u, h, col, mean, m2);
     }
 }
 
@@ -132,27 +170,6 @@ __device__ __forceinline__ PoolCur pool_cursor(const TdnnArgs& a, int64_t row) {
     pc.u = __builtin_amdgcn_readfirstlane(utt_of_row(a.out_map, row));
     pc.end = row_off(a.out_map, pc.u + 1);
     return pc;
-}
-
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc_n(const void* p, int num_bytes) {
-    // uniform by construction (kernel argument + blockIdx-derived offset); readfirstlane makes
-    // that provable so hipcc emits no waterfall loop around the buffer loads
-    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
-    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-    void* q = reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo);
-    return __builtin_amdgcn_make_buffer_rsrc(q, (short)0, __builtin_amdgcn_readfirstlane(num_bytes), 0x00020000);
-}
-
-// descriptor without a range limit (the buffers behind it are padded for every over-read)
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) { return make_rsrc_n(p, 0x7fffffff); }
-
-// descriptor of base + off that ends where the buffer of `total` bytes ends: the hardware range
-// check then returns zeros for every byte past the end, with no instruction spent on it
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc_bounded(const void* base, int64_t off, int64_t total) {
-    int64_t left = total - off;
-    left = left < 0 ? 0 : (left > 0x7fffffff ? 0x7fffffff : left);
-    return make_rsrc_n(static_cast<const char*>(base) + off, (int)left);
 }
 
 }  // namespace xvec

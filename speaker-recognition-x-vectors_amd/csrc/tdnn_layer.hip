@@ -48,7 +48,8 @@ namespace xvec {
 
 constexpr int kBM = 128, kBN = 128;
 constexpr int kStageFloats = (kBM + kBN) * kBK;   // one LDS buffer: A tile then B tile
-constexpr int kLdsBytes = 2 * kStageFloats * 4;
+constexpr int kConstFloats = 3 * kBN;             // bias | scale | shift of the block's 128 channels (epilogue)
+constexpr int kLdsBytes = (2 * kStageFloats + kConstFloats) * 4;
 
 #ifdef XVEC_DIAG
 // Diagnostic build only (make DIAG=1): s_memtime stamps of wave 0 of every block.
@@ -367,7 +368,6 @@ struct Regs {
 
 struct Lane {
     int h, sw, a_rd, b_rd, st_off, r0, c, col;
-    float bias, scale, shift;   // epilogue constants of this lane's channel (fixed for the whole block)
 };
 
 // Once per block: chunk 0 of the first tile -> LDS buffer 0, its first fragments -> set 0,
@@ -440,7 +440,10 @@ __device__ __forceinline__ void process_tile(const TdnnArgs& a, float* smem, Ctx
     // ---- epilogue: bias + ReLU + folded BatchNorm (tdnn_layer.py:30-39)
     // accumulator element e of lane (r, h): row = (e&3) + 8*(e>>2) + 4*h, col = r
     const int col = ln.col;
-    const float bi = ln.bias, sc = ln.scale, sh = ln.shift;
+    // epilogue constants of this lane's channel: three LDS reads per tile instead of three registers held
+    // across the K loop (the pooling and first-layer variants were 3-6 registers over the 256 budget)
+    const float* cst = smem + 2 * kStageFloats + (col - n0);
+    const float bi = cst[0], sc = cst[kBN], sh = cst[2 * kBN];
     // Two phases per row group: (1) all 16 values finished IN PLACE in the accumulator registers,
     // (2) 16 stores issued back to back from those 16 distinct registers, addressed by a per-tile
     // buffer descriptor + one per-lane offset + a scalar row offset.  (Computing each value into a
@@ -546,9 +549,11 @@ __global__ __launch_bounds__(256, 2) void tdnn_kernel(const TdnnArgs a) {
     ln.a_rd = r * kBK;
     ln.b_rd = kBM * kBK + (wave * 32 + r) * kBK;
     ln.col = n0 + wave * 32 + r;
-    ln.bias = a.bias[ln.col];
-    ln.scale = a.scale[ln.col];
-    ln.shift = a.shift[ln.col];
+    if (tid < kBN) {
+        smem[2 * kStageFloats + tid] = a.bias[n0 + tid];
+        smem[2 * kStageFloats + kBN + tid] = a.scale[n0 + tid];
+        smem[2 * kStageFloats + 2 * kBN + tid] = a.shift[n0 + tid];
+    }
 
     Ctx cx;
     cx.g_s = g_begin;
@@ -620,7 +625,6 @@ hipError_t launch_tdnn(const TdnnArgs& a, TdnnVariant v, hipStream_t s) {
         case TdnnVariant::kF32First: return launch_variant<true, false, true, false, false>(a, s);
         case TdnnVariant::kF32: return launch_variant<false, false, true, false, false>(a, s);
         case TdnnVariant::kF32Pool: return launch_variant<false, true, false, false, false>(a, s);
-        case TdnnVariant::kF32PoolStore: return launch_variant<false, true, true, false, false>(a, s);
         case TdnnVariant::kBf16First:
             return x3 ? launch_variant<true, false, true, true, true, true>(a, s) : launch_variant<true, false, true, true, true>(a, s);
         case TdnnVariant::kBf16:

@@ -144,15 +144,6 @@ struct Tile {
     int mr;
 };
 
-// Row offset of a ragged batch through the SCALAR cache.  hipcc loads `offsets[u]` with a vector load even
-// for a provably uniform u (the pointer is not known to be read-only), and the s_waitcnt vmcnt(0) it puts
-// behind that load would drain this kernel's DMA queue; the array is written by the host before the launch.
-__device__ __forceinline__ int64_t sload_i64(const int64_t* p) {
-    int64_t v;
-    asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
-    return v;
-}
-
 // activation source of one tile: descriptor at its first row + this lane's byte offsets of the wave's A piece of
 // acc rows 0..3
 struct Rows {
@@ -435,7 +426,7 @@ __device__ __forceinline__ void store_acc(const f32x16& v, const float4 (&sc)[4]
 // variance ~1e-7*(1 + mean^2/var)), far inside this bf16 path's 1e-2 bar.
 // v0 / v1: the accumulators of this wave's two 32-channel columns for the group at compact row row_g
 // (bias already inside: the accumulators start at it).
-// Returns true when the group lay inside one utterance (exactly four stores were issued).
+// Returns true when the group lay inside one utterance.
 // RAGGED is a template parameter and the utterance index is kept provably wave-uniform on purpose: with
 // a run-time "offsets ? load : multiply" hipcc emitted VECTOR loads of the offsets followed by
 // s_waitcnt vmcnt(0) -- on the fixed-length path too -- and every one of those waits drained the DMA
@@ -456,6 +447,7 @@ __device__ __forceinline__ bool pool_raw_pair(const TdnnArgs& a, const f32x16& v
     }
     const int64_t grp = row_g >> 5;
     const int ld = a.ldy;
+    const __amdgpu_buffer_rsrc_t prs = make_rsrc(a.pool_part);
     if (pc.end >= row_g + 32) {               // the whole group belongs to utterance pc.u
         // two values per instruction where the ISA has one (v_pk_add_f32 / v_pk_fma_f32; the max has none)
         f32x2 p1a = {0.f, 0.f}, p2a = {0.f, 0.f}, p1b = {0.f, 0.f}, p2b = {0.f, 0.f};
@@ -470,16 +462,11 @@ __device__ __forceinline__ bool pool_raw_pair(const TdnnArgs& a, const f32x16& v
         }
         const float s1a = add_halves(p1a.x + p1a.y), s2a = add_halves(p2a.x + p2a.y);
         const float s1b = add_halves(p1b.x + p1b.y), s2b = add_halves(p2b.x + p2b.y);
-        if (h == 0) {
-            float* part = a.pool_part + (grp + pc.u) * (int64_t)(2 * ld);
-            part[col0] = s1a;
-            part[ld + col0] = s2a;
-            part[col0 + 32] = s1b;
-            part[ld + col0 + 32] = s2b;
-        }
+        store_partial(prs, ld, grp + pc.u, h, col0, s1a, s2a);
+        store_partial(prs, ld, grp + pc.u, h, col0 + 32, s1b, s2b);
         return true;
     }
-    for (int u = pc.u; u < m.n_utts; ++u) {   // the group straddles utterances: select each one's rows
+    for (int u = pc.u; u < m.n_utts; u = __builtin_amdgcn_readfirstlane(u + 1)) {   // the group straddles utterances
         const int64_t off = first_row<RAGGED>(m, u);
         if (off >= row_g + 32) break;
         const int64_t end = first_row<RAGGED>(m, u + 1);
@@ -503,13 +490,8 @@ __device__ __forceinline__ bool pool_raw_pair(const TdnnArgs& a, const f32x16& v
         s2a = add_halves(s2a);
         s1b = add_halves(s1b);
         s2b = add_halves(s2b);
-        if (h == 0) {
-            float* part = a.pool_part + (grp + u) * (int64_t)(2 * ld);
-            part[col0] = s1a;
-            part[ld + col0] = s2a;
-            part[col0 + 32] = s1b;
-            part[ld + col0 + 32] = s2b;
-        }
+        store_partial(prs, ld, grp + u, h, col0, s1a, s2a);
+        store_partial(prs, ld, grp + u, h, col0 + 32, s1b, s2b);
     }
     return false;
 }

@@ -114,7 +114,7 @@ Plan make_plan(const xvec_handle* h, int64_t total, int B) {
     p.actB = o;   o += align_up((size_t)p.rows_alloc * nh * 4);
     p.act5 = o;   o += align_up((size_t)p.rows_alloc * (n5 > nh ? n5 : nh) * 4);   // also the fp32 output of xvec_tdnn_layer
     p.part_slots = p.m_pad / 32 + B + 1;
-    p.part = o;   o += align_up((size_t)p.part_slots * 2 * n5 * 4);
+    p.part = o;   o += align_up((size_t)p.part_slots * 2 * n5 * 4);   // (addressed with 32-bit offsets: forward_rows checks < 2 GiB)
     p.pooled = o; o += align_up((size_t)B * 2 * XVEC_POOL_CHANNELS * 4);
     p.seg6 = o;   o += align_up((size_t)B * h->cfg.x_vector_size * 4);
     p.seg7 = o;   o += align_up((size_t)B * h->cfg.x_vector_size * 4);
@@ -312,6 +312,8 @@ int forward_rows(xvec_handle* h, const float* x_rows, int ldx, const int64_t* of
         }
         in = x16;
     }
+    if ((size_t)p.part_slots * 2 * h->geo[4].n_pad * 4 > 0x7fffffffull)
+        return fail(XVEC_ERR_ARG, "batch too large: pooling partials exceed 2 GiB; split it");
     bool raw_pool = false;
     for (int l = 0; l < XVEC_NUM_TDNN; ++l) {
         map.cum += h->geo[l].ctx_span;

@@ -114,7 +114,6 @@ enum class TdnnVariant {
     kF32First,        // fp32, guarded reads of the caller's rows (layer 1)
     kF32,             // fp32 -> fp32
     kF32Pool,         // fp32 -> pooling partials only (layer 5)
-    kF32PoolStore,    // fp32 -> fp32 + pooling partials
     kBf16First,       // layer 1 of the bf16 path: guarded reads of the bf16-converted MFCC rows
     kBf16,            // bf16 -> bf16
     kBf16Pool,        // bf16 -> pooling partials only

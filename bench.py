@@ -123,7 +123,10 @@ def main():
     x = torch.randn((B, T, 24), generator=gen, device=dev, dtype=torch.float32)
     if lengths is not None:
         x *= (torch.arange(T, device=dev)[None, :] < torch.tensor(lengths, device=dev)[:, None])[:, :, None]
-    emb = torch.empty((K * B, 512), device=dev, dtype=torch.float32) if n_local is None else None
+    # the all-gather leg needs the K batches of embeddings in one contiguous buffer; a single rank keeps the
+    # tensor each step returns (the product's deliverable) and makes no extra copy of it
+    emb = torch.empty((K * B, 512), device=dev, dtype=torch.float32) if n_local is None and collective else None
+    kept = [None] * 4
     gathered = torch.empty((world * K * B, 512), device=dev, dtype=torch.float32) if collective and n_local is None else None
 
     waves = fe = None
@@ -133,10 +136,11 @@ def main():
         assert fe(waves).shape == (B, T, 24)
 
     def step(k):
-        if waves is not None:
-            emb[k * B:(k + 1) * B] = model.extract_x_vec(fe(waves))
+        out = model.extract_x_vec(fe(waves)) if waves is not None else model.extract_x_vec(x, lengths=lengths)
+        if emb is not None:
+            emb[k * B:(k + 1) * B] = out
         else:
-            emb[k * B:(k + 1) * B] = model.extract_x_vec(x, lengths=lengths)
+            kept[k & 3] = out
 
     def job():
         # the product's sharded job (extract.extract_sharded): contiguous utterance block per rank,

@@ -87,6 +87,15 @@ __device__ __forceinline__ float4 buf_load16(__amdgpu_buffer_rsrc_t rsrc, int vo
     return make_float4(f.x, f.y, f.z, f.w);
 }
 
+// eight fp32 values -> eight bf16 in the 16 bytes of a staging register (round to nearest even, as pack_rows)
+__device__ __forceinline__ float4 cvt8_bf16(const float4& lo, const float4& hi) {
+    typedef __bf16 bf16x8v __attribute__((ext_vector_type(8)));
+    typedef float f32x8v __attribute__((ext_vector_type(8)));
+    const f32x8v f8 = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    const f32x4 b4 = __builtin_bit_cast(f32x4, __builtin_convertvector(f8, bf16x8v));
+    return make_float4(b4.x, b4.y, b4.z, b4.w);
+}
+
 // per-thread input offsets of the four staging rows (r0 + 32j) of the tile the stream is in: the
 // compact output row p of utterance u reads input rows p + u*span (+ tap shift).  The utterance of
 // the tile's first row is tracked incrementally (cx.u_tile / cx.off_next: tiles only move
@@ -149,14 +158,17 @@ __device__ __forceinline__ void set_tile_rows(const TdnnArgs& a, Ctx& cx) {
 // (the look-ahead of the final chunks re-reads that chunk; the data is never used).
 // Activation descriptor of the tile at row cx.m0.  GUARD (first layer): X is the caller's tensor,
 // not a padded workspace buffer, so the descriptor ends with it and rows past the end read as 0.
-template <bool GUARD>
+template <int GUARD>
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t x_rsrc(const TdnnArgs& a, const Ctx& cx) {
-    const int64_t off = cx.m0 * (int64_t)a.ldx * cx.es;
-    if (GUARD) return make_rsrc_bounded(a.X, off, a.x_bytes ? a.x_bytes : a.x_rows * (int64_t)a.ldx * cx.es);
+    // GUARD == 2: the caller's rows are fp32 and are rounded to bf16 on their way into the staging registers
+    // (the separate pack_rows pass of the bf16 path: 7.4 MB read + 3.7 MB written + a launch per batch)
+    const int src_es = GUARD == 2 ? 4 : cx.es;
+    const int64_t off = cx.m0 * (int64_t)a.ldx * src_es;
+    if (GUARD) return make_rsrc_bounded(a.X, off, a.x_bytes ? a.x_bytes : a.x_rows * (int64_t)a.ldx * src_es);
     return make_rsrc(static_cast<const char*>(a.X) + off);
 }
 
-template <bool GUARD, bool X3>
+template <int GUARD, bool X3>
 __device__ __forceinline__ void advance(const TdnnArgs& a, Ctx& cx, int n_chunks) {
     if (cx.itl + 1 < n_chunks) {
         // taps innermost: consecutive chunks re-read the same 128-byte slab of activation rows,
@@ -220,8 +232,16 @@ __device__ __forceinline__ void advance(const TdnnArgs& a, Ctx& cx, int n_chunks
         if (GUARD) {                                                                                      \
             /* K past the layer's width (the folded taps of the next frame): an offset the descriptor's   \
                range check rejects, so the piece reads as zeros; rows past the tensor: same check */      \
-            const int voff = (cx.kc * BKE + c * (16 / ES) < a.kpt) ? cx.xo##i_ : 0x7ffffff0;              \
-            dst_ = buf_load16(cx.xrsrc, voff, soff);                                                      \
+            const bool ok_ = cx.kc * BKE + c * (16 / ES) < a.kpt;                                         \
+            if constexpr (GUARD == 2) { /* fp32 source: 8 floats -> 8 bf16 */                             \
+                const int voff = ok_ ? 2 * cx.xo##i_ : 0x7ffffff0;                                        \
+                const float4 lo_ = buf_load16(cx.xrsrc, voff, 2 * soff);                                  \
+                const float4 hi_ = buf_load16(cx.xrsrc, voff, 2 * soff + 16);                             \
+                dst_ = cvt8_bf16(lo_, hi_);                                                               \
+            } else {                                                                                      \
+                const int voff = ok_ ? cx.xo##i_ : 0x7ffffff0;                                            \
+                dst_ = buf_load16(cx.xrsrc, voff, soff);                                                  \
+            }                                                                                             \
         } else {                                                                                          \
             dst_ = buf_load16(cx.xrsrc, cx.xo##i_, soff);                                                 \
         }                                                                                                 \
@@ -372,7 +392,7 @@ struct Lane {
 
 // Once per block: chunk 0 of the first tile -> LDS buffer 0, its first fragments -> set 0,
 // chunks 1 and 2 in flight in the two staging sets (bf16x3: chunk 1 in its single set).
-template <bool GUARD, bool INBF, bool X3>
+template <int GUARD, bool INBF, bool X3>
 __device__ __forceinline__ void block_prologue(const TdnnArgs& a, float* smem, Ctx& cx, Regs& rg, const Lane& ln,
                                                int n_chunks) {
     constexpr int G = 4;   // fetch all four row groups: rows past a short first tile are allocated
@@ -406,7 +426,7 @@ __device__ __forceinline__ void block_prologue(const TdnnArgs& a, float* smem, C
 
 // One tile of G row groups (32 frames each) x 128 channels, starting at row group g0.  On entry
 // the pipeline is primed for this tile (block_prologue or the previous tile's last chunks).
-template <int G, bool GUARD, bool POOL, bool STORE, bool INBF, bool OUTBF, bool X3>
+template <int G, int GUARD, bool POOL, bool STORE, bool INBF, bool OUTBF, bool X3>
 __device__ __forceinline__ void process_tile(const TdnnArgs& a, float* smem, Ctx& cx, Regs& rg, const Lane& ln,
                                              int64_t g0, int n0, int n_chunks) {
     constexpr int ES = INBF ? 2 : 4, BKE = 128 / ES;
@@ -500,7 +520,7 @@ __device__ __forceinline__ void process_tile(const TdnnArgs& a, float* smem, Ctx
 #endif
 }
 
-template <bool GUARD, bool POOL, bool STORE, bool INBF, bool OUTBF, bool X3>
+template <int GUARD, bool POOL, bool STORE, bool INBF, bool OUTBF, bool X3>
 __global__ __launch_bounds__(256, 2) void tdnn_kernel(const TdnnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
 #ifdef XVEC_DIAG
@@ -601,7 +621,7 @@ __global__ __launch_bounds__(256, 2) void tdnn_kernel(const TdnnArgs a) {
 #endif
 }
 
-template <bool GUARD, bool POOL, bool STORE, bool INBF, bool OUTBF, bool X3 = false>
+template <int GUARD, bool POOL, bool STORE, bool INBF, bool OUTBF, bool X3 = false>
 static hipError_t launch_variant(const TdnnArgs& a, hipStream_t s) {
     auto kern = tdnn_kernel<GUARD, POOL, STORE, INBF, OUTBF, X3>;
     static LdsOptIn opt;            // per variant and device
@@ -625,6 +645,7 @@ hipError_t launch_tdnn(const TdnnArgs& a, TdnnVariant v, hipStream_t s) {
         case TdnnVariant::kF32First: return launch_variant<true, false, true, false, false>(a, s);
         case TdnnVariant::kF32: return launch_variant<false, false, true, false, false>(a, s);
         case TdnnVariant::kF32Pool: return launch_variant<false, true, false, false, false>(a, s);
+        case TdnnVariant::kBf16FirstSrc32: return launch_variant<2, false, true, true, true>(a, s);
         case TdnnVariant::kBf16First:
             return x3 ? launch_variant<true, false, true, true, true, true>(a, s) : launch_variant<true, false, true, true, true>(a, s);
         case TdnnVariant::kBf16:

@@ -180,7 +180,7 @@ int run_tdnn(xvec_handle* h, int layer, TdnnVariant v, const void* X, int ldx, i
              int64_t x_plane = 0, int64_t y_plane = 0, bool* raw_pool = nullptr) {
     if (raw_pool) *raw_pool = false;
     const bool in16 = v == TdnnVariant::kBf16 || v == TdnnVariant::kBf16Pool || v == TdnnVariant::kBf16ToF32 ||
-                      v == TdnnVariant::kBf16First || v == TdnnVariant::kBf16FirstToF32;
+                      v == TdnnVariant::kBf16First || v == TdnnVariant::kBf16FirstToF32 || v == TdnnVariant::kBf16FirstSrc32;
     const TdnnGeom& g = in16 ? h->geo16[layer] : h->geo[layer];
     TdnnArgs a;
     memset(&a, 0, sizeof(a));
@@ -285,7 +285,9 @@ int forward_rows(xvec_handle* h, const float* x_rows, int ldx, const int64_t* of
     // bf16 mode the MFCC rows are first rounded to bf16 into the workspace (bf16x3: split into a hi
     // and a lo plane; every activation buffer then holds two bf16 planes in the space of one fp32).
     // Layer 5 carries the statistics-pooling epilogue: its [frames,1500] output stays on chip.
-    const TdnnVariant v1 = b16 ? TdnnVariant::kBf16First : TdnnVariant::kF32First;
+    // (plain bf16: layer 1 reads the fp32 rows itself and rounds them in its staging path; bf16x3 needs the
+    // hi/lo split pass)
+    const TdnnVariant v1 = x3 ? TdnnVariant::kBf16First : b16 ? TdnnVariant::kBf16FirstSrc32 : TdnnVariant::kF32First;
     const TdnnVariant vm = b16 ? TdnnVariant::kBf16 : TdnnVariant::kF32;
     const TdnnVariant v5 = b16 ? TdnnVariant::kBf16Pool : TdnnVariant::kF32Pool;
     // every layer's output is compact: utterance u keeps len_u - cum frames after `cum` frames of
@@ -300,16 +302,12 @@ int forward_rows(xvec_handle* h, const float* x_rows, int ldx, const int64_t* of
     int ld_in = ldx;
     const int64_t act_plane = p.rows_alloc * (int64_t)nh * 2;        // bytes of one bf16 plane of an activation buffer
     int64_t in_plane = 0;
-    if (b16) {   // [total, ldx] fp32 -> bf16 (same row stride in elements)
-        if (p.total > 0x7fffffff) return fail(XVEC_ERR_ARG, "too many frames for one bf16 batch");
+    if (b16 && p.total > 0x7fffffff) return fail(XVEC_ERR_ARG, "too many frames for one bf16 batch");
+    if (x3) {    // [total, ldx] fp32 -> bf16 hi and lo planes (same row stride in elements)
         StageTimer t(h, T_PACK, s);
         void* x16 = ws + p.x16;
-        if (x3) {
-            in_plane = p.rows_alloc * (int64_t)ldx * 2;
-            HIP_TRY(launch_pack_rows_split(x_rows, p.total, ldx, ldx, in_plane / 2, x16, s));
-        } else {
-            HIP_TRY(launch_pack_rows(x_rows, nullptr, 1, (int)p.total, ldx, ldx, x16, true, s));
-        }
+        in_plane = p.rows_alloc * (int64_t)ldx * 2;
+        HIP_TRY(launch_pack_rows_split(x_rows, p.total, ldx, ldx, in_plane / 2, x16, s));
         in = x16;
     }
     if ((size_t)p.part_slots * 2 * h->geo[4].n_pad * 4 > 0x7fffffffull)

@@ -115,6 +115,7 @@ enum class TdnnVariant {
     kF32,             // fp32 -> fp32
     kF32Pool,         // fp32 -> pooling partials only (layer 5)
     kBf16First,       // layer 1 of the bf16 path: guarded reads of the bf16-converted MFCC rows
+    kBf16FirstSrc32,  // the same reading the caller's fp32 rows, rounded to bf16 on the way in (no pack pass)
     kBf16,            // bf16 -> bf16
     kBf16Pool,        // bf16 -> pooling partials only
     kBf16ToF32,       // bf16 -> fp32 (per-layer test entry: layer 5, and every layer in bf16x3)

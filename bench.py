@@ -65,6 +65,11 @@ def main():
     ap.add_argument("--frames", type=int, default=300)
     ap.add_argument("--cpu-budget", type=float, default=40.0,
                     help="seconds of CPU-baseline work over its four legs (B=1/64 x all cores/1 thread; 0 = skip)")
+    ap.add_argument("--preroll", type=float, default=0.5,
+                    help="seconds the path runs UNTIMED before the W warm-up steps, so that the GPU has left its idle "
+                         "power state when the clock starts: the driver's 5+20 steps are 10-70 ms of work, shorter than "
+                         "the ramp (same kernels, bf16: 540 k embeddings/s after 5 warm-up steps, 619 k after 1000; "
+                         "fp32 +0.9 %).  0 = off.  The timed region is unchanged: exactly K steps between barriers")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the secondary legs of the default line (configs[4] bf16 and configs[2] ragged figures)")
     ap.add_argument("--force-collective", action="store_true",
@@ -154,6 +159,17 @@ def main():
         if collective:
             dist.barrier()
 
+    def preroll(fn, seconds=None):
+        # untimed: keep the device busy for `seconds` (see --preroll)
+        seconds = args.preroll if seconds is None else seconds
+        t_end = time.perf_counter() + seconds
+        while time.perf_counter() < t_end:
+            for _ in range(8):
+                fn()
+            torch.cuda.synchronize(dev)
+
+    if n_local is None:
+        preroll(lambda: step(0))
     for _ in range(W):
         model.extract_x_vec(x, lengths=lengths)
     if collective:   # warm the collective too (communicator setup is not part of a step)
@@ -203,9 +219,10 @@ def main():
         dt_pcie = time.perf_counter() - t1
         # the product's pipelined form (extract.stream_x_vectors: next batch's H2D on a side stream)
         if lengths is None:
-            # warm-up long enough to touch every slot of the pipeline's rings (depth + 1 device inputs and pinned
-            # result buffers: first-use hipMalloc / hipHostMalloc cost milliseconds and synchronise the device)
-            for _ in xa.extract.stream_x_vectors(model, (x_host for _ in range(8))):
+            # warm-up as long as the timed call: the first ~50 batches a process sends through the three-stream
+            # pipeline run at about half speed whatever was done before (0.78 vs 0.43 ms per bf16 batch; an 8-batch
+            # warm-up that touched every ring slot did not change that, a 50-batch one does)
+            for _ in xa.extract.stream_x_vectors(model, (x_host for _ in range(max(K_pcie, 50)))):
                 pass
             torch.cuda.synchronize(dev)
             t2 = time.perf_counter()
@@ -257,6 +274,7 @@ def main():
         m16 = xa.XVectorModel(precision="bf16")
         m16.load_state_dict(sd)
         m16 = m16.to(dev).eval()
+        preroll(lambda: m16.extract_x_vec(x))
         for _ in range(5):
             m16.extract_x_vec(x)
         torch.cuda.synchronize(dev)
@@ -281,6 +299,7 @@ def main():
         xr *= (torch.arange(Tr, device=dev)[None, :] < torch.tensor(lens_np, device=dev)[:, None])[:, :, None]
         ll = lens_np.tolist()
         K3 = min(K, 20)
+        preroll(lambda: model.extract_x_vec(xr, lengths=ll), min(args.preroll, 0.25))
         for _ in range(3):
             model.extract_x_vec(xr, lengths=ll)
         torch.cuda.synchronize(dev)
@@ -365,6 +384,7 @@ def main():
                        "graph_replay_embeddings_per_s_per_gpu": round(K * B / dt_graph, 1) if dt_graph else None,
                        "pcie_inclusive_overlapped_embeddings_per_s_per_gpu":
                            round(K_pcie * B / dt_pcie_ovl, 1) if dt_pcie_ovl else None,
+                       "preroll_s": args.preroll if n_local is None else 0.0,
                        "sharding": f"utterance-sharded x{world}"
                        + (", one all-gather of [K*B,512] fp32 in the timed region" if collective else ""),
                        **secondary},

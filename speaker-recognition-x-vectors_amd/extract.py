@@ -134,6 +134,18 @@ def to_records(x_vecs: torch.Tensor, labels, ids) -> List[tuple]:
     return [(i, int(l), np.array(v, dtype=np.float64)) for v, l, i in zip(host, labels, ids)]
 
 
+_SIDE = {}
+
+
+def _side_streams(dev):
+    """The copy streams of a device, created once: every torch stream has its own block pool, so a fresh pair
+    per call would send the input ring to hipMalloc (which synchronises the device) call after call."""
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    if key not in _SIDE:
+        _SIDE[key] = (torch.cuda.Stream(dev), torch.cuda.Stream(dev))
+    return _SIDE[key]
+
+
 def stream_x_vectors(model, host_batches: Iterable[torch.Tensor], device=None, depth: int = 3):
     """Overlapped extraction from HOST batches: yields the fp32 [B, D] x-vectors of every batch as
     host tensors, in input order.
@@ -162,18 +174,22 @@ def stream_x_vectors(model, host_batches: Iterable[torch.Tensor], device=None, d
     if depth < 1:
         raise ValueError("stream_x_vectors: depth must be >= 1")
     compute = torch.cuda.current_stream(dev)
-    h2d, d2h = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    h2d, d2h = _side_streams(dev)
     n_ring = depth + 1
     slots = [None] * n_ring      # device inputs
     consumed = [None] * n_ring   # event: the batch that read the slot has been computed
+    # one event per slot and hop, re-recorded every time round the ring (no hipEventCreate/Destroy per batch)
+    arrived_ev = [torch.cuda.Event() for _ in range(n_ring)]
+    done_ev = [torch.cuda.Event() for _ in range(n_ring)]
+    landed_ev = [torch.cuda.Event() for _ in range(n_ring)]
     results = [None] * n_ring    # page-locked host result buffers [rows, D]
-    inflight = []                # (landed event, host buffer, rows)
+    inflight = []                # (landed event, host buffer, rows, device result)
 
     def locked(rows, D, dtype):
         return torch.empty((max(rows, 1), D), dtype=dtype, pin_memory=True)
 
     def harvest():
-        ev, buf, n = inflight.pop(0)
+        ev, buf, n, _dev_out = inflight.pop(0)     # the device result is released here, after its copy landed
         ev.synchronize()                           # returns at once when query() was already true
         # a plain single-threaded memcpy: tensor.clone() goes through torch's intra-op thread pool, and waking
         # that pool (one thread per visible CPU -- 256 on the GPU box, under a 16-CPU quota) next to the
@@ -181,26 +197,34 @@ def stream_x_vectors(model, host_batches: Iterable[torch.Tensor], device=None, d
         return torch.from_numpy(buf[:n].numpy().copy())
 
     def pipeline():
+        try:
+            yield from batches()
+        finally:
+            # the slots go back to the copy stream's pool when this frame dies: order that stream behind the
+            # batches that read them (also when the consumer abandons the generator half way)
+            h2d.wait_stream(compute)
+
+    def batches():
         k = 0
         for xb in host_batches:
             if xb.device.type != "cpu":
                 raise ValueError("stream_x_vectors: expected host tensors (device batches: call extract_x_vec directly)")
             i = k % n_ring
             fresh = slots[i] is None or slots[i].shape != xb.shape or slots[i].dtype != xb.dtype
-            if fresh:
-                slots[i] = None
-                slots[i] = torch.empty(xb.shape, dtype=xb.dtype, device=dev)   # from the current stream's pool
             with torch.cuda.stream(h2d):
-                if fresh:
-                    h2d.wait_stream(compute)           # whatever used that memory before is done
-                elif consumed[i] is not None:
+                if consumed[i] is not None:
                     h2d.wait_event(consumed[i])        # the slot's previous batch has been read
+                if fresh:
+                    # from the COPY stream's pool: whatever held that memory before was released in this stream's
+                    # order, so the first batches need no wait on the compute stream either
+                    slots[i] = None
+                    slots[i] = torch.empty(xb.shape, dtype=xb.dtype, device=dev)
                 slots[i].copy_(xb, non_blocking=True)
-                arrived = torch.cuda.Event()
+                arrived = arrived_ev[i]
                 arrived.record(h2d)
             compute.wait_event(arrived)
             out = model.extract_x_vec(slots[i])        # enqueued on the current stream
-            done = torch.cuda.Event()
+            done = done_ev[i]
             done.record(compute)
             consumed[i] = done
             n, D = out.shape
@@ -209,16 +233,18 @@ def stream_x_vectors(model, host_batches: Iterable[torch.Tensor], device=None, d
             with torch.cuda.stream(d2h):               # not the compute stream: there the copy would queue
                 d2h.wait_event(done)                   # behind the younger batches already enqueued
                 results[i][:n].copy_(out, non_blocking=True)
-                landed = torch.cuda.Event()
+                landed = landed_ev[i]                  # its previous batch was handed out: at most `depth` in flight
                 landed.record(d2h)
-            out.record_stream(d2h)                     # its memory returns to the pool only after the copy
-            inflight.append((landed, results[i], n))
+            # `out` stays referenced until its copy has landed.  (out.record_stream(d2h) instead parks the block
+            # in the allocator until an event query says the side stream is done with it; meanwhile the next
+            # batches' results come from hipMalloc, which synchronises the device: 0.63 -> 0.48 ms per bf16
+            # batch over the first calls, profiles/diag/stream_probe5.py)
+            inflight.append((landed, results[i], n, out))
             k += 1
             while inflight and (len(inflight) > depth or inflight[0][0].query()):
                 yield harvest()
         while inflight:
             yield harvest()
-        compute.wait_stream(h2d)                       # the slots return to the current stream's pool
 
     yield from pipeline()
 

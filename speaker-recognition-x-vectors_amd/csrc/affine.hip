@@ -8,6 +8,7 @@
 // Operands are read once per block straight into registers (16 B per lane, 64 contiguous bytes per
 // row and instruction); they are small enough to stay in L2.
 #include "xvec_internal.h"
+#include <algorithm>
 
 namespace xvec {
 
@@ -93,12 +94,158 @@ __global__ __launch_bounds__(64 * kAffWaves) void affine_f32_kernel(const float*
 }
 #undef AFF_MFMA4
 
+// ---- split-K form (the forward path, which has scratch memory to offer) -----------------------------------------
+// The kernel above reads a 16-row strip of x and of W per 16x16 tile: 4 flop per operand byte, 196 MB of L2
+// reads for segment_layer6 at M=256 (x is 3 MB, W 6 MB) -- 21 us, bound by those reads.  Here a block owns a
+// 64x64 tile (16 flop per byte, 48 MB) and a K range: M=256, N=512, K=3000 -> 4 x 8 tiles x 16 ranges = 512
+// blocks of four waves, each wave a 32x32 quadrant on v_mfma_f32_32x32x2_f32 (13 us + 4.6 us for the reduction;
+// 8 to 16 ranges measure the same, 4 ranges 26 us: profiles/diag/aff_sweep.py).  The operand tiles go through LDS:
+// 16 lanes fetch 256 contiguous bytes of a row (a lane-per-row fetch straight into the fragment layout touches
+// 32 cache lines per instruction for 32 useful bytes each -- that version took 20 us), rows padded to 68 floats so
+// that the 16-byte fragment reads are conflict-free.  Partial tiles go to scratch [S][M][N] and are summed in
+// range order by affine_reduce_kernel (deterministic; bias and ReLU there).  S == 1 (many utterances: the tiles
+// alone fill the chip) writes y directly.
+typedef float f32x16v __attribute__((ext_vector_type(16)));
+constexpr int kAfsLd = 68;                       // LDS row stride in floats (64 + 4)
+constexpr int kAfsTile = 64 * kAfsLd;            // one operand tile
+
+template <bool DIRECT>
+__global__ __launch_bounds__(256, 2) void affine_splitk_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                               const float* __restrict__ b, float* __restrict__ out, int M,
+                                                               int N, int K, int relu, int trips_per_split, int tn,
+                                                               int tiles, int S) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * kAfsTile];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, kh = lane >> 5;
+    // Workgroups go to the eight XCDs round-robin and every XCD has its own L2: with the K ranges dealt out the
+    // same way (range s on XCD s % 8) an XCD fetches only ITS eighth of x and W from HBM.  With the tiles spread
+    // over the XCDs instead every L2 pulled all 9 MB in -- 72 MB over the fabric, 14 us for a 5 us kernel.
+    int split = 0, tile = blockIdx.x;
+    if (!DIRECT) {
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        split = xcd + 8 * (idx / tiles);
+        tile = idx % tiles;
+        if (split >= S) return;
+    }
+    const int bm0 = (tile / tn) * 64, bn0 = (tile % tn) * 64;
+    const int trips = (K + 63) / 64;
+    const int t_lo = split * trips_per_split, t_hi = min(trips, t_lo + trips_per_split);
+
+    // staging map: 16 lanes per row (16 x 16 B = the trip's 64 floats), 16 rows per pass, 4 passes per operand
+    const int s_row = tid >> 4, s_c = (tid & 15) * 4;
+    const float* xs[4];
+    const float* ws[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {                // clamped rows: results discarded
+        xs[p] = x + (int64_t)min(bm0 + s_row + 16 * p, M - 1) * K;
+        ws[p] = W + (int64_t)min(bn0 + s_row + 16 * p, N - 1) * K;
+    }
+    // two register sets: the loads of trips t+1 and t+2 are in flight while trip t is multiplied (a block has only
+    // a few trips, so the memory latency is paid about once instead of once per trip)
+    float4 ra0[4], rb0[4], ra1[4], rb1[4];
+#define AFS_LOAD(S_, t_)                                         \
+    _Pragma("unroll") for (int p = 0; p < 4; ++p) {              \
+        ra##S_[p] = ld4<true>(xs[p], 64 * (t_) + s_c, K);        \
+        rb##S_[p] = ld4<true>(ws[p], 64 * (t_) + s_c, K);        \
+    }
+#define AFS_TRIP(S_, t_)                                                                           \
+    {                                                                                              \
+        __syncthreads(); /* the previous trip's fragment reads are done */                         \
+        _Pragma("unroll") for (int p = 0; p < 4; ++p) {                                            \
+            *reinterpret_cast<float4*>(lds + (s_row + 16 * p) * kAfsLd + s_c) = ra##S_[p];         \
+            *reinterpret_cast<float4*>(lds + kAfsTile + (s_row + 16 * p) * kAfsLd + s_c) = rb##S_[p]; \
+        }                                                                                          \
+        __syncthreads();                                                                           \
+        if ((t_) + 2 < t_hi) AFS_LOAD(S_, (t_) + 2)                                                \
+        _Pragma("unroll") for (int g = 0; g < 8; ++g) { /* lane half kh owns k = 8g + 4kh .. +3 */  \
+            const float4 c = *reinterpret_cast<const float4*>(fa + 8 * g);                         \
+            const float4 d = *reinterpret_cast<const float4*>(fb + 8 * g);                         \
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(c.x, d.x, acc0, 0, 0, 0);                  \
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(c.y, d.y, acc1, 0, 0, 0);                  \
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(c.z, d.z, acc0, 0, 0, 0);                  \
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(c.w, d.w, acc1, 0, 0, 0);                  \
+        }                                                                                          \
+    }
+    f32x16v acc0, acc1;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc0[e] = acc1[e] = 0.f;
+    const float* fa = lds + (32 * (wave >> 1) + i) * kAfsLd + 4 * kh;
+    const float* fb = lds + kAfsTile + (32 * (wave & 1) + i) * kAfsLd + 4 * kh;
+    if (t_lo < t_hi) AFS_LOAD(0, t_lo)
+    if (t_lo + 1 < t_hi) AFS_LOAD(1, t_lo + 1)
+    for (int t = t_lo; t < t_hi; t += 2) {
+        AFS_TRIP(0, t)
+        if (t + 1 < t_hi) AFS_TRIP(1, t + 1)
+    }
+#undef AFS_TRIP
+#undef AFS_LOAD
+    // accumulator element e of lane (i, kh): row = (e&3) + 8*(e>>2) + 4*kh, col = i
+    const int m0 = bm0 + 32 * (wave >> 1), col = bn0 + 32 * (wave & 1) + i;
+    if (col >= N) return;
+    float* dst = DIRECT ? out : out + (int64_t)split * M * N;
+    const float bias = DIRECT ? b[col] : 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int row = m0 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+        if (row < M) {
+            float v = acc0[e] + acc1[e] + bias;
+            if (DIRECT && relu) v = fmaxf(v, 0.f);
+            dst[(int64_t)row * N + col] = v;
+        }
+    }
+}
+
+// y = act(b + sum over the S ranges, in range order); one float4 of y per thread (N % 4 == 0)
+__global__ __launch_bounds__(256) void affine_reduce_kernel(const float* __restrict__ part, const float* __restrict__ b,
+                                                            float* __restrict__ y, int64_t MN, int N, int S, int relu) {
+    const int64_t q = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (q >= MN) return;
+    float4 v = *reinterpret_cast<const float4*>(b + (int)(q % N));
+    int s = 0;
+    for (; s + 4 <= S; s += 4) {                 // four independent loads in flight, summed in order
+        const float4 p0 = *reinterpret_cast<const float4*>(part + (s + 0) * MN + q);
+        const float4 p1 = *reinterpret_cast<const float4*>(part + (s + 1) * MN + q);
+        const float4 p2 = *reinterpret_cast<const float4*>(part + (s + 2) * MN + q);
+        const float4 p3 = *reinterpret_cast<const float4*>(part + (s + 3) * MN + q);
+        v.x = (((v.x + p0.x) + p1.x) + p2.x) + p3.x;
+        v.y = (((v.y + p0.y) + p1.y) + p2.y) + p3.y;
+        v.z = (((v.z + p0.z) + p1.z) + p2.z) + p3.z;
+        v.w = (((v.w + p0.w) + p1.w) + p2.w) + p3.w;
+    }
+    for (; s < S; ++s) {
+        const float4 p = *reinterpret_cast<const float4*>(part + s * MN + q);
+        v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+    }
+    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    *reinterpret_cast<float4*>(y + q) = v;
+}
+
 hipError_t launch_affine_f32(const float* x, const float* W, const float* b, float* y, int M, int N,
-                             int K, int relu, hipStream_t s) {
+                             int K, int relu, hipStream_t s, float* scratch, size_t scratch_bytes) {
     if (M <= 0 || N <= 0) return hipSuccess;
+    const bool vec16 = (K % 4 == 0) && (((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(W)) & 15) == 0);
+    const int64_t MN = (int64_t)M * N;
+    if (scratch && vec16 && N % 4 == 0 && ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(b)) & 15) == 0) {
+        const int tm = (M + 63) / 64, tn = (N + 63) / 64, trips = (K + 63) / 64;
+        int S = (512 + tm * tn - 1) / (tm * tn);                     // about two blocks per CU
+        S = std::min(S, std::max(trips / 2, 1));                     // at least two trips per range
+        S = (int)std::min<int64_t>(std::min(S, 16), (int64_t)(scratch_bytes / 4) / MN);
+        if (S <= 1 && tm * tn >= 256) {
+            affine_splitk_kernel<true><<<dim3(tn * tm), 256, 0, s>>>(x, W, b, y, M, N, K, relu, trips, tn, tn * tm, 1);
+            return hipGetLastError();
+        }
+        if (S > 1) {
+            const int tps = (trips + S - 1) / S;
+            S = (trips + tps - 1) / tps;
+            const int s_pad = (S + 7) & ~7;                       // ranges s_pad-S..: blocks that exit at once
+            affine_splitk_kernel<false><<<dim3(s_pad * tn * tm), 256, 0, s>>>(x, W, b, scratch, M, N, K, relu, tps, tn,
+                                                                               tn * tm, S);
+            affine_reduce_kernel<<<(unsigned)((MN / 4 + 255) / 256), 256, 0, s>>>(scratch, b, y, MN, N, S, relu);
+            return hipGetLastError();
+        }
+    }
     dim3 grid((N + 15) / 16, (M + 15) / 16);
-    const bool vec = (K % 4 == 0) && (((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(W)) & 15) == 0);
-    if (vec)
+    if (vec16)
         affine_f32_kernel<true><<<grid, 64 * kAffWaves, 0, s>>>(x, W, b, y, M, N, K, relu);
     else
         affine_f32_kernel<false><<<grid, 64 * kAffWaves, 0, s>>>(x, W, b, y, M, N, K, relu);

@@ -20,6 +20,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 }
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 // x + (x of lane ^ 32) in every lane: v_permlane32_swap exchanges the upper half of one copy with
 // the lower half of the other in the vector ALU (ds_bpermute would be an LDS round trip plus a
@@ -49,6 +50,42 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc_bounded(const void* 
     int64_t left = total - off;
     left = left < 0 ? 0 : (left > 0x7fffffff ? 0x7fffffff : left);
     return make_rsrc_n(static_cast<const char*>(base) + off, (int)left);
+}
+
+// ReLU + folded BatchNorm on one accumulator whose REGISTERS are channels (store variant): element e =
+// channel (e&3) + 8*(e>>2) + 4*h of the 32-channel block.  The bias is already inside (the accumulators
+// start at it); scale / shift of the lane's 16 channels are passed in registers, read from LDS once per
+// column and tile (an LDS read holds a wave's issue ~30-40 cycles: twelve per accumulator were the
+// largest single item of this epilogue).
+__device__ __forceinline__ void store_acc(const f32x16& v, const float4 (&sc)[4], const float4 (&sh)[4],
+                                          __amdgpu_buffer_rsrc_t yrsrc, int y_voff, int y_soff) {
+    unsigned pk[8];
+    typedef float f32x2v __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+        const float y0 = fmaf(fmaxf(v[4 * gq + 0], 0.f), sc[gq].x, sh[gq].x);
+        const float y1 = fmaf(fmaxf(v[4 * gq + 1], 0.f), sc[gq].y, sh[gq].y);
+        const float y2 = fmaf(fmaxf(v[4 * gq + 2], 0.f), sc[gq].z, sh[gq].z);
+        const float y3 = fmaf(fmaxf(v[4 * gq + 3], 0.f), sc[gq].w, sh[gq].w);
+        pk[2 * gq] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{y0, y1}, bf16x2));
+        pk[2 * gq + 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{y2, y3}, bf16x2));
+    }
+    // lane halves hold channels 8g..8g+3 (h=0) and 8g+4..8g+7 (h=1) of register group g: swapping the
+    // upper half of group g with the lower half of group g+1 leaves 8 consecutive channels per lane
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) {
+        auto r0 = __builtin_amdgcn_permlane32_swap(pk[4 * pr + 0], pk[4 * pr + 2], false, false);
+        auto r1 = __builtin_amdgcn_permlane32_swap(pk[4 * pr + 1], pk[4 * pr + 3], false, false);
+        const u32x4 o = {r0[0], r1[0], r0[1], r1[1]};
+        __builtin_amdgcn_raw_buffer_store_b128(o, yrsrc, y_voff, y_soff + pr * 32, 0);
+        // A 128-bit buffer store reads its data registers a cycle or two after it issues; a vector instruction
+        // that overwrites them in the very next slot wins the race in some lanes.  hipcc (ROCm 7.2) pads that
+        // hazard only when the store's soffset is NOT a register -- with the row offset in an SGPR, as here, it
+        // scheduled `v_max_f32 v24, ...` straight behind `buffer_store_dwordx4 v[24:27], ..., s70 offen` and
+        // lanes 12-15/28-31 of ~1 row in 10^4 stored the NEXT accumulator's raw bits (profiles/diag/swap_debug.py).
+        // The data registers are kept alive across one wait state:
+        asm volatile("s_nop 1" ::"v"(o));
+    }
 }
 
 // One float of a pooling partial: slot `slot` (32-row group + utterance), plane 0/1, column col -- as a buffer

@@ -290,10 +290,16 @@ __device__ __forceinline__ void advance(const TdnnArgs& a, Ctx& cx, int n_chunks
     slot_                                                                                                 \
     SB();
 // bf16: one MFMA per row group consumes the whole 16-byte fragment (k-step of 16)
+// (SWAP: weights as the first operand -- the accumulator's registers are then channels and its lanes frames,
+// the layout store_acc turns into 16-byte stores)
 #define XV_MFB(i_, f_, q_, P_)                                                                            \
     if constexpr (G > i_) {                                                                               \
-        acc##i_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, rg.fa##i_##_##f_),   \
-                                                          __builtin_bit_cast(bf16x8, rg.gb##q_##_##P_), acc##i_, 0, 0, 0); \
+        if constexpr (SWAP)                                                                               \
+            acc##i_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, rg.gb##q_##_##P_), \
+                                                              __builtin_bit_cast(bf16x8, rg.fa##i_##_##f_), acc##i_, 0, 0, 0); \
+        else                                                                                              \
+            acc##i_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, rg.fa##i_##_##f_), \
+                                                              __builtin_bit_cast(bf16x8, rg.gb##q_##_##P_), acc##i_, 0, 0, 0); \
     }                                                                                                     \
     SB();
 // one k-group with 16 slots.  fp32: 4 k components x 4 row groups = 16 MFMAs, one slot behind each;
@@ -431,9 +437,25 @@ __device__ __forceinline__ void process_tile(const TdnnArgs& a, float* smem, Ctx
                                              int64_t g0, int n0, int n_chunks) {
     constexpr int ES = INBF ? 2 : 4, BKE = 128 / ES;
     const int h = ln.h, sw = ln.sw, a_rd = ln.a_rd, b_rd = ln.b_rd, st_off = ln.st_off, c = ln.c;
+    // bf16 in, bf16 out, one plane, stored: the transposed product (channels in the accumulator's registers), so
+    // that a lane ends up with 8 consecutive channels of one frame = one 16-byte store.  With frames in the
+    // registers a lane holds ONE channel and every value is its own 2-byte store: 64 store instructions per
+    // wave and tile -- layer 1, whose K loop is two chunks long, spent most of its 30 us issuing them.
+    constexpr bool SWAP = INBF && OUTBF && !X3 && STORE && !POOL;
     f32x16 acc0, acc1, acc2, acc3;
+    // this wave's 32 channels, the lane half's 4 of every 8 (SWAP): bias | scale | shift tables in LDS
+    const float* cstw = smem + 2 * kStageFloats + (ln.col - n0 - (int)(threadIdx.x & 31)) + 4 * ln.h;
+    if constexpr (SWAP) {      // accumulators start at the bias of their register's channel
 #pragma unroll
-    for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; acc2[e] = 0.f; acc3[e] = 0.f; }
+        for (int gq = 0; gq < 4; ++gq) {
+            const float4 b4 = *reinterpret_cast<const float4*>(cstw + 8 * gq);
+            acc0[4 * gq] = b4.x; acc0[4 * gq + 1] = b4.y; acc0[4 * gq + 2] = b4.z; acc0[4 * gq + 3] = b4.w;
+        }
+        acc1 = acc0; acc2 = acc0; acc3 = acc0;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; acc2[e] = 0.f; acc3[e] = 0.f; }
+    }
 
 #ifdef XVEC_DIAG
     SB();
@@ -504,7 +526,22 @@ __device__ __forceinline__ void process_tile(const TdnnArgs& a, float* smem, Ctx
         }                                                                                                 \
         if (POOL) pool_group(a, acc##i_, m0 + i_ * 32, h, col, sh, cx.pool);                                           \
     }
-    XV_EPI(0) XV_EPI(1) XV_EPI(2) XV_EPI(3)
+    if constexpr (SWAP) {
+        float4 sc4[4], sh4[4];
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            sc4[gq] = *reinterpret_cast<const float4*>(cstw + kBN + 8 * gq);
+            sh4[gq] = *reinterpret_cast<const float4*>(cstw + 2 * kBN + 8 * gq);
+        }
+        // lane = frame r of the group, 8 channels per store: (r, h) -> channels 8h.. (+16 for the second store)
+        const int voff = ((int)(threadIdx.x & 31) * a.ldy + (ln.col - n0 - (int)(threadIdx.x & 31)) + 8 * h) * 2;
+        if constexpr (G > 0) store_acc(acc0, sc4, sh4, yrsrc, voff, 0 * 32 * a.ldy * 2);
+        if constexpr (G > 1) store_acc(acc1, sc4, sh4, yrsrc, voff, 1 * 32 * a.ldy * 2);
+        if constexpr (G > 2) store_acc(acc2, sc4, sh4, yrsrc, voff, 2 * 32 * a.ldy * 2);
+        if constexpr (G > 3) store_acc(acc3, sc4, sh4, yrsrc, voff, 3 * 32 * a.ldy * 2);
+    } else {
+        XV_EPI(0) XV_EPI(1) XV_EPI(2) XV_EPI(3)
+    }
 #undef XV_EPI
 #ifdef XVEC_DIAG
     SB();

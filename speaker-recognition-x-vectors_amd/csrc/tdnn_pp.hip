@@ -45,7 +45,6 @@ constexpr int kThreads = 512;
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* lds_ptr;
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ i32x4 make_srd(const void* p) {
     const unsigned long long v = reinterpret_cast<unsigned long long>(p);
@@ -386,35 +385,6 @@ struct Lane {
         kstep(a, k2);                                                               \
         ++wq;                                                                       \
     }
-
-// ReLU + folded BatchNorm on one accumulator whose REGISTERS are channels (store variant): element e =
-// channel (e&3) + 8*(e>>2) + 4*h of the 32-channel block.  The bias is already inside (the accumulators
-// start at it); scale / shift of the lane's 16 channels are passed in registers, read from LDS once per
-// column and tile (an LDS read holds a wave's issue ~30-40 cycles: twelve per accumulator were the
-// largest single item of this epilogue).
-__device__ __forceinline__ void store_acc(const f32x16& v, const float4 (&sc)[4], const float4 (&sh)[4],
-                                          __amdgpu_buffer_rsrc_t yrsrc, int y_voff, int y_soff) {
-    unsigned pk[8];
-    typedef float f32x2v __attribute__((ext_vector_type(2)));
-#pragma unroll
-    for (int gq = 0; gq < 4; ++gq) {
-        const float y0 = fmaf(fmaxf(v[4 * gq + 0], 0.f), sc[gq].x, sh[gq].x);
-        const float y1 = fmaf(fmaxf(v[4 * gq + 1], 0.f), sc[gq].y, sh[gq].y);
-        const float y2 = fmaf(fmaxf(v[4 * gq + 2], 0.f), sc[gq].z, sh[gq].z);
-        const float y3 = fmaf(fmaxf(v[4 * gq + 3], 0.f), sc[gq].w, sh[gq].w);
-        pk[2 * gq] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{y0, y1}, bf16x2));
-        pk[2 * gq + 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{y2, y3}, bf16x2));
-    }
-    // lane halves hold channels 8g..8g+3 (h=0) and 8g+4..8g+7 (h=1) of register group g: swapping the
-    // upper half of group g with the lower half of group g+1 leaves 8 consecutive channels per lane
-#pragma unroll
-    for (int pr = 0; pr < 2; ++pr) {
-        auto r0 = __builtin_amdgcn_permlane32_swap(pk[4 * pr + 0], pk[4 * pr + 2], false, false);
-        auto r1 = __builtin_amdgcn_permlane32_swap(pk[4 * pr + 1], pk[4 * pr + 3], false, false);
-        const u32x4 o = {r0[0], r1[0], r0[1], r1[1]};
-        __builtin_amdgcn_raw_buffer_store_b128(o, yrsrc, y_voff, y_soff + pr * 32, 0);
-    }
-}
 
 // Fused statistics pooling for the pooling variant (main.py:59-63), frames in the accumulator registers and
 // the channel on the lane.  The epilogue runs in the open here (both waves of a SIMD are in it at the same

@@ -339,27 +339,30 @@ int forward_rows(xvec_handle* h, const float* x_rows, int ldx, const int64_t* of
         HIP_TRY(launch_pool_finalize(f, s));
     }
     const int xv = h->cfg.x_vector_size, K6 = 2 * XVEC_POOL_CHANNELS;
+    // the frame-level activations are dead from here on: layers 1-4's buffers serve as split-K scratch
+    float* scr = actA;
+    const size_t scr_bytes = (p.actB - p.actA) * 2;                 // actA and actB are adjacent
     if (mode == XVEC_MODE_XVEC6) {
         StageTimer t(h, T_SEG6, s);
-        HIP_TRY(launch_affine_f32(pooled, h->affW[0], h->affB[0], out, B, xv, K6, 0, s));
+        HIP_TRY(launch_affine_f32(pooled, h->affW[0], h->affB[0], out, B, xv, K6, 0, s, scr, scr_bytes));
         return XVEC_OK;
     }
     {
         StageTimer t(h, T_SEG6, s);
-        HIP_TRY(launch_affine_f32(pooled, h->affW[0], h->affB[0], s6, B, xv, K6, 1, s));
+        HIP_TRY(launch_affine_f32(pooled, h->affW[0], h->affB[0], s6, B, xv, K6, 1, s, scr, scr_bytes));
     }
     if (mode == XVEC_MODE_XVEC7) {
         StageTimer t(h, T_SEG7, s);
-        HIP_TRY(launch_affine_f32(s6, h->affW[1], h->affB[1], out, B, xv, xv, 0, s));
+        HIP_TRY(launch_affine_f32(s6, h->affW[1], h->affB[1], out, B, xv, xv, 0, s, scr, scr_bytes));
         return XVEC_OK;
     }
     {
         StageTimer t(h, T_SEG7, s);
-        HIP_TRY(launch_affine_f32(s6, h->affW[1], h->affB[1], s7, B, xv, xv, 1, s));
+        HIP_TRY(launch_affine_f32(s6, h->affW[1], h->affB[1], s7, B, xv, xv, 1, s, scr, scr_bytes));
     }
     {
         StageTimer t(h, T_OUT, s);
-        HIP_TRY(launch_affine_f32(s7, h->affW[2], h->affB[2], out, B, h->cfg.num_classes, xv, 0, s));
+        HIP_TRY(launch_affine_f32(s7, h->affW[2], h->affB[2], out, B, h->cfg.num_classes, xv, 0, s, scr, scr_bytes));
     }
     return XVEC_OK;
 }

@@ -147,9 +147,10 @@ struct PoolFinalizeArgs {
 };
 hipError_t launch_pool_finalize(const PoolFinalizeArgs& a, hipStream_t s);
 
-// y[M,N] = act(x[M,K] . W[N,K]^T + b)   (PyTorch nn.Linear layout, fp32 MFMA)
+// y[M,N] = act(x[M,K] . W[N,K]^T + b)   (PyTorch nn.Linear layout, fp32 MFMA).  With `scratch` (device memory the
+// call may overwrite) a small problem is split over K into scratch and reduced by a second kernel.
 hipError_t launch_affine_f32(const float* x, const float* W, const float* b, float* y, int M, int N,
-                             int K, int relu, hipStream_t s);
+                             int K, int relu, hipStream_t s, float* scratch = nullptr, size_t scratch_bytes = 0);
 
 // weight packing
 hipError_t launch_pack_tdnn(const float* W, const float* bias, const float* g, const float* be,

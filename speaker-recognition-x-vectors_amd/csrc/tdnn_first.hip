@@ -1,0 +1,240 @@
+// Layer 1 of the bf16 path (reference tdnn_layer.py:26-60 with context [-2..2] on 24 MFCCs): K = 5 x 24 = 120
+// inputs per frame, 512 outputs -- 0.3 % of the path's flops and 77 MB of bf16 output per 256 x 300-frame batch.
+// It is a streaming kernel, not a GEMM tile problem: in the 128x128 kernel (tdnn_layer.hip) a tile's K loop is
+// two chunks long and a tile costs 8.4k cycles (3.3k K loop, mostly load latency behind two barriers; 2.3k
+// epilogue; 2.8k tile switch) for 1k cycles of MFMA -- 31-33 us, where a plain fill of the same 77.6 MB takes
+// 15-17 us (profiles/diag/src/write_bw.hip).  This kernel: 25-28 us on the same boxes.
+//
+// Here the weights never move: a wave owns 128 output channels and keeps its 128 x 128 bf16 weight block in
+// registers (32 fragments = 128 VGPRs) for the whole launch; a block of four waves covers the 512 channels of
+// one 32-frame group at a time.  The group's input -- 32 windows of 120 consecutive floats, 96 B apart -- is
+// fetched by the 256 threads together (one 16-wide k-step of one frame each, 64 contiguous bytes), rounded to
+// bf16 and parked in an 8 KiB LDS tile (two tiles: the next group is fetched into registers while this one is
+// multiplied; one barrier per group).  Accumulator PAIRS share their lanes' channels: lane r of the even
+// accumulator is channel 2r of a 64-channel block, lane r of the odd one channel 2r+1 (which column of W a lane
+// multiplies is only a matter of which fragment bytes it loaded), so one v_cvt_pk_bf16_f32 joins the two values
+// into the dword that belongs at column 2r and a store instruction writes two whole 128-byte row segments --
+// the shape the memory system takes at full rate.  (The transposed product with 16-byte stores per lane, which
+// touches 32 rows x 32 B per instruction, measured the same here; what did cost time was every wave waiting
+// for its stores to be acknowledged at each group's barrier, see XF_LDS_BARRIER.)  No per-tile descriptors,
+// no tile switch; the utterance bookkeeping (input row = output row + 4 x utterance index) is two scalar
+// compares per group on the fixed-length path.
+//
+// Shapes: n_pad == 512, one folded tap with k_pad == 128 (input_size * 5 <= 128, rows contiguous: ldx ==
+// input_size) and 16-byte aligned rows; run_tdnn falls back to the 128x128 kernel otherwise.
+#include "tdnn_common.h"
+
+namespace xvec {
+namespace first {
+
+constexpr int kRowB = 272;                 // LDS bytes per frame: 128 bf16 + 16 (conflict-free 16-byte fragment reads)
+constexpr int kTileB = 32 * kRowB;
+constexpr int kConstFloats = 3 * 512;      // bias | scale | shift
+
+__device__ __forceinline__ u32x4 cvt8(const u32x4& lo, const u32x4& hi) {
+    typedef float f32x2v __attribute__((ext_vector_type(2)));
+    u32x4 o;
+    o[0] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{__uint_as_float(lo[0]), __uint_as_float(lo[1])}, bf16x2));
+    o[1] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{__uint_as_float(lo[2]), __uint_as_float(lo[3])}, bf16x2));
+    o[2] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{__uint_as_float(hi[0]), __uint_as_float(hi[1])}, bf16x2));
+    o[3] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{__uint_as_float(hi[2]), __uint_as_float(hi[3])}, bf16x2));
+    return o;
+}
+
+// staged input of one thread: k-step `ks` (16 values) of frame `rr` of the group
+struct Staged {
+    u32x4 q0, q1, q2, q3;                  // SRC32: 16 floats; else q0, q1 = 16 bf16
+};
+
+template <bool RAGGED>
+__device__ __forceinline__ int64_t first_row_of(const RowMap& m, int u) {
+    u = __builtin_amdgcn_readfirstlane(u);
+    if (RAGGED) return sload_i64(m.offsets + u) - (int64_t)u * m.cum;
+    return (int64_t)u * (m.fixed_T - m.cum);
+}
+
+// utterance cursor of a block: u = utterance of the group's first row, end = first output row of utterance u+1
+struct Cur {
+    int u;
+    int64_t end;
+};
+
+template <bool SRC32, bool RAGGED>
+__device__ __forceinline__ void fetch(const TdnnArgs& a, int64_t g, Cur& cu, int rr, int ks, Staged& st) {
+    const RowMap& m = a.out_map;
+    const int64_t m0 = g * 32;
+    const int n_last = m.n_utts - 1;
+    while (cu.end <= m0 && cu.u < n_last) {
+        cu.u = __builtin_amdgcn_readfirstlane(cu.u + 1);
+        cu.end = first_row_of<RAGGED>(m, cu.u + 1);
+    }
+    // boundaries inside the group: frame rr lies c utterances past cu.u
+    int c = 0;
+    {
+        int u = cu.u;
+        int64_t nxt = cu.end;
+        while (nxt < m0 + 32 && u < n_last) {
+            c += (m0 + rr >= nxt) ? 1 : 0;
+            u = __builtin_amdgcn_readfirstlane(u + 1);
+            nxt = first_row_of<RAGGED>(m, u + 1);
+        }
+    }
+    constexpr int ES = SRC32 ? 4 : 2;
+    // descriptor at the group's first input row (64-bit), bounded by the end of the caller's tensor: reads past
+    // it return zeros; the lane offset is small (a group's rows + the utterances it skips)
+    const int64_t row0 = m0 + (int64_t)cu.u * a.span;
+    const int64_t total = a.x_bytes ? a.x_bytes : a.x_rows * (int64_t)a.ldx * ES;
+    const __amdgpu_buffer_rsrc_t xr = make_rsrc_bounded(a.X, row0 * a.ldx * ES, total);
+    const int voff = ((rr + c * a.span) * a.ldx + 16 * ks) * ES;
+    st.q0 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, voff, 0, 0));
+    st.q1 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, voff, 16, 0));
+    if (SRC32) {
+        st.q2 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, voff, 32, 0));
+        st.q3 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, voff, 48, 0));
+    }
+}
+
+// round (SRC32), blank the K tail (values past kpt belong to the next frame and meet zero weights, but
+// 0 x Inf is not 0) and park the 32 bytes in the LDS tile
+template <bool SRC32>
+__device__ __forceinline__ void park(const TdnnArgs& a, char* tile, int rr, int ks, const Staged& st) {
+    u32x4 lo, hi;
+    if (SRC32) {
+        lo = cvt8(st.q0, st.q1);
+        hi = cvt8(st.q2, st.q3);
+    } else {
+        lo = st.q0;
+        hi = st.q1;
+    }
+    const int k0 = 16 * ks;
+    if (k0 + 16 > a.kpt) {                 // only the last k-step(s) of a row: pairs of bf16 per dword
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const int k = k0 + 2 * d;
+            if (k >= a.kpt) lo[d] = 0u; else if (k + 1 >= a.kpt) lo[d] &= 0xffffu;
+            if (k + 8 >= a.kpt) hi[d] = 0u; else if (k + 9 >= a.kpt) hi[d] &= 0xffffu;
+        }
+    }
+    *reinterpret_cast<u32x4*>(tile + rr * kRowB + ks * 32) = lo;
+    *reinterpret_cast<u32x4*>(tile + rr * kRowB + ks * 32 + 16) = hi;
+}
+
+template <bool SRC32, bool RAGGED>
+__global__ __launch_bounds__(256, 2) void tdnn_first_kernel(const TdnnArgs a) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * kTileB + kConstFloats * 4];
+    float* cst = reinterpret_cast<float*>(smem + 2 * kTileB);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably uniform: scalar fragment offsets
+    const int r = lane & 31, h = lane >> 5;
+    for (int i = tid; i < 512; i += 256) {
+        cst[i] = a.bias[i];
+        cst[512 + i] = a.scale[i];
+        cst[1024 + i] = a.shift[i];
+    }
+    // this wave's weights: channels [128*wave, +128).  Accumulator cg, lane r <-> channel
+    //   ch = 128*wave + 64*(cg>>1) + 2*r + (cg&1);
+    // the fragment-major packing (pack.hip) keeps W[32*ct + l][16*ks + 8*h ..+7] at ((ct*8 + ks)*64 + l + 32*h)*16 B
+    u32x4 wf[4][8];
+    {
+        const __amdgpu_buffer_rsrc_t wr = make_rsrc(a.Wf);
+#pragma unroll
+        for (int cg = 0; cg < 4; ++cg) {
+            const int ch = 128 * wave + 64 * (cg >> 1) + 2 * r + (cg & 1);
+            const int voff = ((ch >> 5) * 8 * 64 + (ch & 31) + 32 * h) * 16;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks)
+                wf[cg][ks] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wr, voff, ks * 1024, 0));
+        }
+    }
+    // contiguous range of 32-frame groups per block
+    const int64_t g_begin = a.groups_total * (int64_t)blockIdx.x / gridDim.x;
+    const int64_t g_end = a.groups_total * (int64_t)(blockIdx.x + 1) / gridDim.x;
+    if (g_begin >= g_end) return;
+    Cur cu;
+    cu.u = __builtin_amdgcn_readfirstlane(utt_of_row(a.out_map, g_begin * 32));
+    cu.end = first_row_of<RAGGED>(a.out_map, cu.u + 1);
+    const int rr = tid >> 3, sks = tid & 7;        // staging: frame rr, k-step sks
+    // Two groups of look-ahead: loads and stores share the wave's in-order vmcnt counter, so waiting for loads
+    // issued AFTER a group's 32 stores would wait for those stores to be acknowledged by memory (several us at
+    // full write rate: 6 us per group, no faster than the 128x128 kernel).  The loads of group g+2 are issued
+    // before the stores of group g, and the wait for group g+1's loads leaves the newer operations in flight.
+    Staged sa, sb;
+    fetch<SRC32, RAGGED>(a, g_begin, cu, rr, sks, sa);
+    park<SRC32>(a, smem, rr, sks, sa);
+    if (g_begin + 1 < g_end) fetch<SRC32, RAGGED>(a, g_begin + 1, cu, rr, sks, sb);
+    __syncthreads();                               // constants + tile 0 visible
+
+    const char* frag = smem + r * kRowB + 16 * h;  // A operand of lane (r, h): frame r, k = 16*ks + 8*h ..+7
+    // epilogue constants of this lane's four channels (pair p: 128*wave + 64*p + 2r, +1)
+    float2 bi[2], sc[2], sh[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const float* c0 = cst + 128 * wave + 64 * p + 2 * r;
+        bi[p] = *reinterpret_cast<const float2*>(c0);
+        sc[p] = *reinterpret_cast<const float2*>(c0 + 512);
+        sh[p] = *reinterpret_cast<const float2*>(c0 + 1024);
+    }
+    // accumulator element e of lane (r, h): frame (e&3) + 8*(e>>2) + 4*h; the lane's dword sits at column 2r
+    const int y_voff = (4 * h * a.ldy + 128 * wave + 2 * r) * 2;
+    // __syncthreads() is `s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier`: it would hold every wave until its 32 stores
+    // of the group are acknowledged by memory.  Only the LDS traffic has to be ordered here.
+#define XF_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // one group: MFMAs on LDS tile `buf_`, park the staged group g+1 (ST_PARK) into the other tile, fetch group
+    // g+2 into the set that was parked last time (ST_FETCH), epilogue + stores
+#define XF_GROUP(g_, buf_, ST_PARK, ST_FETCH)                                                                     \
+    {                                                                                                             \
+        if ((g_) + 2 < g_end) fetch<SRC32, RAGGED>(a, (g_) + 2, cu, rr, sks, ST_FETCH);                           \
+        f32x16 acc[4];                                                                                            \
+        _Pragma("unroll") for (int cg = 0; cg < 4; ++cg)                                                          \
+            _Pragma("unroll") for (int e = 0; e < 16; ++e) acc[cg][e] = 0.f;                                      \
+        const char* tile = frag + (buf_) * kTileB;                                                                \
+        _Pragma("unroll") for (int ks = 0; ks < 8; ++ks) {                                                        \
+            const u32x4 xf = *reinterpret_cast<const u32x4*>(tile + ks * 32);                                     \
+            _Pragma("unroll") for (int cg = 0; cg < 4; ++cg)                                                      \
+                acc[cg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, xf),                 \
+                                                                  __builtin_bit_cast(bf16x8, wf[cg][ks]), acc[cg], 0, 0, 0); \
+        }                                                                                                         \
+        if ((g_) + 1 < g_end) park<SRC32>(a, smem + ((buf_) ^ 1) * kTileB, rr, sks, ST_PARK);                     \
+        /* bias + ReLU + folded BatchNorm (tdnn_layer.py:30-39); rows of the group at g*32 (the row buffer is */  \
+        /* padded past the last valid frame) */                                                                   \
+        const __amdgpu_buffer_rsrc_t yr = make_rsrc(static_cast<char*>(a.Y) + (g_) * 32 * (int64_t)a.ldy * 2);    \
+        _Pragma("unroll") for (int p = 0; p < 2; ++p)                                                             \
+            _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                                      \
+                const float v0 = fmaf(fmaxf(acc[2 * p][e] + bi[p].x, 0.f), sc[p].x, sh[p].x);                     \
+                const float v1 = fmaf(fmaxf(acc[2 * p + 1][e] + bi[p].y, 0.f), sc[p].y, sh[p].y);                 \
+                const unsigned pk = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{v0, v1}, bf16x2)); \
+                __builtin_amdgcn_raw_buffer_store_b32(pk, yr, y_voff, (((e & 3) + 8 * (e >> 2)) * a.ldy + 64 * p) * 2, 0); \
+            }                                                                                                     \
+        XF_LDS_BARRIER() /* the other tile is written, this one read by every wave */                            \
+    }
+    typedef float f32x2v __attribute__((ext_vector_type(2)));
+    for (int64_t g = g_begin; g < g_end; g += 2) {
+        XF_GROUP(g, 0, sb, sa)
+        if (g + 1 < g_end) XF_GROUP(g + 1, 1, sa, sb)
+    }
+#undef XF_GROUP
+#undef XF_LDS_BARRIER
+}
+
+}  // namespace first
+
+bool tdnn_first_applicable(const TdnnArgs& a, int es) {
+    return a.ldy == 512 && a.k_pad == 128 && a.n_taps == 1 && a.kpt <= 128 && a.terms == 1 && (a.ldx * es) % 16 == 0 &&
+           (reinterpret_cast<uintptr_t>(a.X) & 15) == 0 && a.groups_total > 0;
+}
+
+hipError_t launch_tdnn_first(const TdnnArgs& a, bool src32, int num_cu, hipStream_t s) {
+    const int64_t want = 2 * (int64_t)num_cu;      // one block per CU measured 30 us against 28
+    const int grid = (int)(a.groups_total < want ? a.groups_total : want);
+    const bool ragged = a.out_map.offsets != nullptr;
+    if (src32) {
+        if (ragged) first::tdnn_first_kernel<true, true><<<grid, 256, 0, s>>>(a);
+        else first::tdnn_first_kernel<true, false><<<grid, 256, 0, s>>>(a);
+    } else {
+        if (ragged) first::tdnn_first_kernel<false, true><<<grid, 256, 0, s>>>(a);
+        else first::tdnn_first_kernel<false, false><<<grid, 256, 0, s>>>(a);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace xvec

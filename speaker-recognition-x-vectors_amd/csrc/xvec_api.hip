@@ -254,6 +254,13 @@ int run_tdnn(xvec_handle* h, int layer, TdnnVariant v, const void* X, int ldx, i
             return XVEC_OK;
         }
     }
+    if (h->use_pp && layer == 0 && (v == TdnnVariant::kBf16First || v == TdnnVariant::kBf16FirstSrc32)) {
+        const bool src32 = v == TdnnVariant::kBf16FirstSrc32;
+        if (tdnn_first_applicable(a, src32 ? 4 : 2)) {
+            HIP_TRY(launch_tdnn_first(a, src32, h->num_cu, s));
+            return XVEC_OK;
+        }
+    }
     HIP_TRY(launch_tdnn(a, v, s));
     return XVEC_OK;
 }

@@ -348,9 +348,9 @@ def main():
         # bf16x3 the 128x128 kernel (csrc/tdnn_layer.hip)
         pp16 = args.dtype == "bf16" and B * (T - 14) >= 3 * 64 * 128
         dom_kernel = ("xvec::pp::tdnn_pp_kernel<false> (layers 2-4, bf16 MFMA, LDS-DMA operands)" if pp16 else
-                      "xvec::tdnn_kernel<false,false,true,true,true> (layers 2-4, bf16 MFMA"
+                      "xvec::tdnn_kernel<0,false,true,true,true,X3> (layers 2-4, bf16 MFMA"
                       + (", three products per k-step)" if args.dtype == "bf16x3" else ")") if bf else
-                      "xvec::tdnn_kernel<false,false,true,false,false> (layers 2-4, fp32 MFMA)")
+                      "xvec::tdnn_kernel<0,false,true,false,false,false> (layers 2-4, fp32 MFMA)")
         value = n_done / dt
         # HBM bytes per launch of the dominant kernel come from the committed rocprofv3 --pmc pass of
         # this same command (profiles/traffic.json, written by profiles/summarize_pmc.py); counters
@@ -359,9 +359,8 @@ def main():
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
             tj = tj[args.dtype]                             # one section per arithmetic (bf16x3: no PMC pass yet)
-            key = {"fp32": "tdnn_kernel<false, false, true, false, false",
-                   "bf16": "pp::tdnn_pp_kernel<false" if pp16 else "tdnn_kernel<false, false, true, true, true"}[args.dtype]
-            key = next(k for k in tj if k.startswith(key) and not k.rstrip(">").endswith(", true, true, true, true"))
+            key = {"fp32": "tdnn_kernel<0, false, true, false, false, false>",
+                   "bf16": "pp::tdnn_pp_kernel<false>" if pp16 else "tdnn_kernel<0, false, true, true, true, false>"}[args.dtype]
             traffic, traffic_src = tj[key]["hbm_bytes_per_launch"], tj["source"]
         except (OSError, KeyError, ValueError, StopIteration):
             pass

@@ -140,7 +140,9 @@ int xvec_affine(xvec_handle* h, int which, const float* x, int32_t M, int relu, 
  * stream.  xvec_get_timings synchronises on the last event and returns milliseconds:
  * ms[0..4] TDNN layers 1-5 (layer 5 includes its fused pooling epilogue), ms[5] pooling
  * finalize / stand-alone pooling, ms[6..8] segment_layer6 / 7 / output (0 if not run),
- * ms[9] input packing; *n = 10. */
+ * ms[9] input packing (ragged batches, channel padding, the bf16x3 hi/lo split; 0 when the first layer
+ * reads the caller's tensor directly, as in fp32 and bf16 on fixed-length batches); a segment-layer figure
+ * covers both launches of its split-K form; *n = 10. */
 int xvec_set_profiling(xvec_handle* h, int on);
 int xvec_get_timings(xvec_handle* h, float* ms, int* n);
 

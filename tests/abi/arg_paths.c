@@ -1,0 +1,93 @@
+/* Argument-error paths of the C ABI under AddressSanitizer / UBSan (host build of the library, no device code:
+ * `make -C speaker-recognition-x-vectors_amd/csrc asan`).  Every call here must be rejected BEFORE the library
+ * touches a device -- or, where it has to ask the runtime first (xvec_create with a valid configuration on a
+ * machine without a GPU), fail with XVEC_ERR_HIP and leave nothing behind.  SURVEY section 5: the reference is
+ * Python and has no sanitizer story; the boundary this repo adds is C, so its error paths get one.
+ * Exit code 0 = every expectation held (the sanitizers abort the process otherwise). */
+#include <stdio.h>
+#include <string.h>
+#include "xvec_hip.h"
+#include "xvec_score.h"
+
+static int failures = 0;
+#define EXPECT(cond)                                                                 \
+    do {                                                                             \
+        if (!(cond)) {                                                               \
+            ++failures;                                                              \
+            fprintf(stderr, "%s:%d: expectation failed: %s\n", __FILE__, __LINE__, #cond); \
+        }                                                                            \
+    } while (0)
+
+int main(void) {
+    xvec_handle* h = (xvec_handle*)0;
+    xvec_cfg cfg = {24, 512, 1211, 512, 1, 0};
+    float buf[64];
+    int n = 0;
+    memset(buf, 0, sizeof buf);
+
+    /* handle creation */
+    EXPECT(xvec_create((const xvec_cfg*)0, &h) == XVEC_ERR_ARG);
+    EXPECT(xvec_create(&cfg, (xvec_handle**)0) == XVEC_ERR_ARG);
+    EXPECT(strlen(xvec_last_error()) > 0);
+    {
+        xvec_cfg bad = cfg;
+        bad.hidden_size = 0;
+        EXPECT(xvec_create(&bad, &h) == XVEC_ERR_ARG && h == 0);
+        bad = cfg;
+        bad.input_size = -3;
+        EXPECT(xvec_create(&bad, &h) == XVEC_ERR_ARG && h == 0);
+        bad = cfg;
+        bad.hidden_size = 1 << 20;
+        EXPECT(xvec_create(&bad, &h) == XVEC_ERR_ARG && h == 0);
+        bad = cfg;
+        bad.device = 1 << 20;                        /* no such device: a runtime error, not a crash */
+        int rc = xvec_create(&bad, &h);
+        EXPECT((rc == XVEC_ERR_HIP || rc == XVEC_ERR_STATE) && h == 0);
+    }
+    /* every entry point with a null handle */
+    EXPECT(xvec_load_tdnn(0, 0, buf, buf, buf, buf, buf, buf, 1e-5f, 0) == XVEC_ERR_ARG);
+    EXPECT(xvec_load_affine(0, XVEC_SEG6, buf, buf, 0) == XVEC_ERR_ARG);
+    EXPECT(xvec_workspace_bytes(0, 1000, 4) == 0);
+    EXPECT(xvec_forward(0, buf, 0, 1, 32, XVEC_MODE_XVEC6, XVEC_F32, buf, buf, sizeof buf, 0) == XVEC_ERR_ARG);
+    EXPECT(xvec_forward_packed(0, buf, 0, 1, XVEC_MODE_XVEC6, XVEC_F32, buf, buf, sizeof buf, 0) == XVEC_ERR_ARG);
+    EXPECT(xvec_tdnn_layer(0, 0, buf, 1, 32, XVEC_F32, buf, buf, sizeof buf, 0) == XVEC_ERR_ARG);
+    EXPECT(xvec_affine(0, XVEC_SEG6, buf, 1, 0, buf, 0) == XVEC_ERR_ARG);
+    EXPECT(xvec_set_profiling(0, 1) == XVEC_ERR_ARG);
+    EXPECT(xvec_get_timings(0, buf, &n) == XVEC_ERR_ARG);
+    xvec_destroy(0);                                 /* a no-op by contract */
+    /* handle-free entry points */
+    EXPECT(xvec_stat_pool(0, 0, 1, 10, 8, buf, 0) == XVEC_ERR_ARG);
+    EXPECT(xvec_stat_pool(buf, 0, 0, 10, 8, buf, 0) == XVEC_ERR_ARG);
+    EXPECT(xvec_stat_pool(buf, 0, 70000, 10, 8, buf, 0) == XVEC_ERR_ARG);
+    /* MFCC plan */
+    {
+        xvec_mfcc_plan* p = 0;
+        xvec_mfcc_cfg m = {16000, 0.025f, 0.01f, 24, 26, 512, 0.f, 0.f, 0.97f, 22, 1, 0};
+        EXPECT(xvec_mfcc_create(0, &p) == XVEC_ERR_ARG);
+        EXPECT(xvec_mfcc_create(&m, 0) == XVEC_ERR_ARG);
+        xvec_mfcc_cfg bad = m;
+        bad.nfft = 500;                              /* not a power of two */
+        EXPECT(xvec_mfcc_create(&bad, &p) == XVEC_ERR_ARG && p == 0);
+        bad = m;
+        bad.numcep = 40;                             /* more cepstra than filters */
+        EXPECT(xvec_mfcc_create(&bad, &p) == XVEC_ERR_ARG && p == 0);
+        EXPECT(xvec_mfcc(0, buf, 1, 16000, buf, 0) == XVEC_ERR_ARG);
+        EXPECT(xvec_mfcc_frames(0, 16000) <= 0);
+        xvec_mfcc_destroy(0);
+        EXPECT(strlen(xvec_mfcc_last_error()) > 0);
+    }
+    /* scoring */
+    {
+        double d[8] = {0};
+        EXPECT(xvec_gemm_nt_f64(0, 4, d, 4, 2, 2, 4, 0, 0, 0.0, 1.0, d, 2, 0) != XVEC_OK);
+        EXPECT(xvec_cosine_score(0, 2, d, 2, 4, d, 0, 0, 0) != XVEC_OK);
+        EXPECT(xvec_score_workspace_bytes(-1, 2, 4) == 0);
+        EXPECT(strlen(xvec_score_last_error()) > 0);
+    }
+    if (failures) {
+        fprintf(stderr, "%d expectation(s) failed\n", failures);
+        return 1;
+    }
+    printf("abi argument paths: ok (%s)\n", xvec_version());
+    return 0;
+}

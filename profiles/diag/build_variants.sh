@@ -7,7 +7,7 @@ cd "$(dirname "$0")/../../speaker-recognition-x-vectors_amd/csrc"
 out=../../profiles/diag/bin
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -Wno-pass-failed -Wno-inline-asm"
 mkdir -p $out /tmp/xv_base /tmp/xv_diag
-for f in tdnn_layer pool affine pack mfcc score xvec_api; do
+for f in tdnn_layer tdnn_first pool affine pack mfcc score xvec_api; do
   /opt/rocm/bin/hipcc $FLAGS -c $f.hip -o /tmp/xv_base/$f.o &
 done
 /opt/rocm/bin/hipcc $FLAGS -DXVEC_DIAG -c tdnn_layer.hip -o /tmp/xv_diag/tdnn_layer.o &

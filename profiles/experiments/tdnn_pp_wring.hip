@@ -1,0 +1,770 @@
+// Frame-level TDNN layer, bf16 operands / fp32 accumulation, for the large batches of the bf16 path
+// (BASELINE configs[4]): the same implicit GEMM as tdnn_layer.hip (tdnn_layer.py:26-41 of the
+// reference: context gather -> Linear -> ReLU -> eval BatchNorm, optional fused statistics pooling,
+// main.py:59-63) with a machine mapping built for the bf16 matrix rate.
+//
+// Why a second mapping.  The 128x128-tile kernel of tdnn_layer.hip moves 512 B from L2 per
+// v_mfma_f32_32x32x16_bf16; at the bf16 rate that is ~52 B/clk per CU against the ~64 B/clk the
+// L2 -> CU path delivers, so loads and MFMAs add up instead of overlapping (DESIGN.md 8 [4]).  Here:
+//   * ONE 512-thread block per CU, tile = up to 256 frames x 256 channels, K in 64-wide tiles
+//     (128-byte rows): 256 B per MFMA, half the L2 traffic.
+//   * both operands go global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds: no staging registers,
+//     no ds_write), 1-KiB pieces of 8 rows x 128 B; the 16-byte-chunk XOR swizzle that makes the
+//     ds_read_b128 fragment reads conflict-free is applied on the SOURCE address (the LDS image of
+//     a DMA piece is lane-linear).  Two 64-KiB LDS buffers (K-tile parity), refilled slot by slot
+//     two K-tiles ahead behind COUNTED s_waitcnt vmcnt -- the queue is never drained in the loop.
+//   * 8 waves = 2 groups (frames halves) x 4 (64-channel columns); wave tile = MR x 2 accumulators
+//     of 32x32 (MR = 3 or 4 per tile: 192 or 256 frames).  The two waves of a SIMD belong to
+//     different groups and run one barrier apart ("ping-pong"): while one issues its 16 MFMAs of a
+//     phase, the other reads its next fragments from LDS and issues its DMA pieces, then they swap.
+//     A phase = 2 accumulator rows x 2 columns x 4 k-steps; 2 phases per K-tile.
+//   * persistent: a block owns a contiguous range of 64-frame units of one 256-channel column and
+//     cuts it into tiles of 3 or 4 units, as equal as possible (a partial round of fixed 256-row
+//     tiles would idle a quarter of the chip at B=256: 584 tiles over 256 CUs).
+//   * store epilogue: the accumulators hold CHANNELS in their registers and frames on the lanes
+//     (weights are the MFMA A operand), so a lane owns 4 consecutive channels per register group;
+//     bias + ReLU + folded BatchNorm from per-channel constants kept in LDS, packed to bf16,
+//     v_permlane32_swap pairs the lane halves and every store is 16 bytes.
+//     Pooling epilogue (layer 5): operands swapped (frames in the registers, channel on the lane),
+//     so the per-(32-frame group, utterance) mean / M2 partials are register sums (pool_group).
+// The next tile's first K-tiles are requested before the epilogue, so the DMA flies under it.
+#include "tdnn_common.h"
+
+namespace xvec {
+namespace pp {
+
+constexpr int kRowB = 128;                        // one K-tile slab of one row: 64 bf16
+constexpr int kAccRowB = 32 * kRowB;              // 32 frames: 4 KiB = 4 DMA pieces
+constexpr int kABytes = 2 * 3 * kAccRowB;         // activation buffer [group][acc row][32 frames]: 24 KiB, two of them
+constexpr int kWBytes = 256 * kRowB;              // 256 channels: 32 KiB = 32 DMA pieces
+constexpr int kWOff = 2 * kABytes;                // weight ring: three K-tiles
+constexpr int kConstOff = kWOff + 3 * kWBytes;
+constexpr int kConstBytes = 3 * 256 * 4;          // bias | scale | shift of the block's 256 channels
+constexpr int kLdsBytes = kConstOff + kConstBytes;
+constexpr int kThreads = 512;
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_ptr;
+
+__device__ __forceinline__ i32x4 make_srd(const void* p) {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    i32x4 d;
+    d.x = (int)__builtin_amdgcn_readfirstlane((unsigned)v);
+    d.y = (int)(__builtin_amdgcn_readfirstlane((unsigned)(v >> 32)) & 0xffffu);   // stride 0
+    d.z = 0x7fffffff;                                                            // num_records (bytes)
+    d.w = 0x00020000;
+    return d;
+}
+
+// One DMA piece: 64 lanes x 16 B from per-lane source offsets to 1 KiB of LDS at `dst` (wave
+// uniform).  Inline asm on purpose: hipcc would wait vmcnt(0) for the builtin form before the
+// next ds_read; this way the pieces are invisible to its bookkeeping and are waited for by hand
+// (counted vmcnt before the barrier that publishes them).
+__device__ __forceinline__ void dma16(const i32x4& rsrc, unsigned dst, int voff, int soff) {
+    // dst / soff / rsrc are SALU results (no VALU-written SGPR feeds the load: no wait states needed
+    // beyond the one after the M0 write); M0 is declared clobbered instead of saved and restored
+    asm volatile(
+        "s_mov_b32 m0, %0\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %1, %2, %3 offen lds"
+        :
+        : "s"(dst), "v"(voff), "s"(rsrc), "s"(soff)
+        : "memory", "m0");
+}
+
+#ifdef XVEC_DIAG
+// Diagnostic build only (make DIAG=1): s_memtime stamps of one wave per group, summed per segment kind.
+// slot = 16 * group + kind; kinds: 0-5 phase 0 (issue, wait, barrier, mfma, barrier, -), 6-11 phase 1
+__device__ unsigned long long g_pp_diag[2 * 512 * 32];   // [pooling variant][block][group][kind]
+#define PP_STAMP(k_)                                                                               \
+    {                                                                                              \
+        SB();                                                                                      \
+        unsigned long long now_;                                                                   \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory");              \
+        dsum[k_] += now_ - dprev;                                                                  \
+        dprev = now_;                                                                              \
+        SB();                                                                                      \
+    }
+#else
+#define PP_STAMP(k_)
+#endif
+#ifdef XVEC_KNOCK
+// Timing-only knock-outs, compile time (-DXVEC_KNOCK=mask; results are garbage):
+//   bit 0: no DMA pieces in the K loop     bit 1: no LDS fragment reads (fragments stay zero)
+//   bit 2: no epilogue (stores / pooling)
+#define PP_KNOCK_DMA ((XVEC_KNOCK & 1) != 0)
+#define PP_KNOCK_RD ((XVEC_KNOCK & 2) != 0)
+#define PP_KNOCK_EPI ((XVEC_KNOCK & 4) != 0)
+#define PP_KNOCK_RDW ((XVEC_KNOCK & 8) != 0)     // bit 3: no W fragment reads only
+#define PP_KNOCK_RDA ((XVEC_KNOCK & 16) != 0)    // bit 4: no A fragment reads only
+#else
+#define PP_KNOCK_RDW false
+#define PP_KNOCK_RDA false
+#define PP_KNOCK_DMA false
+#define PP_KNOCK_RD false
+#define PP_KNOCK_EPI false
+#endif
+// lgkmcnt(0) as the BUILTIN (0xC07F = lgkmcnt 0, vmcnt / expcnt untouched): hipcc's wait-count pass sees it and
+// knows every earlier LDS read is back.  As inline asm it did not, and put lgkmcnt(3..0) waits for
+// fragments read a segment earlier in front of the MFMAs -- behind the freshly issued prefetch reads,
+// which serialised those reads with the MFMAs they were meant to hide under.
+#define PP_WAIT_LGKM()                          \
+    {                                           \
+        SB();                                   \
+        __builtin_amdgcn_s_waitcnt(0xC07F);     \
+        SB();                                   \
+    }
+#define PP_WAIT_VM(n_) asm volatile("s_waitcnt vmcnt(" #n_ ")" ::: "memory")
+// counted wait whose count is only known at run time (it depends on the next tile's height): one of the few
+// values the request schedule can produce; anything else waits for everything (stricter, never wrong)
+#define PP_WAIT_VM_RT(n_)                                        \
+    {                                                            \
+        const int nn_ = (n_);                                    \
+        if (nn_ == 11) { PP_WAIT_VM(11); }                       \
+        else if (nn_ == 10) { PP_WAIT_VM(10); }                  \
+        else if (nn_ == 8) { PP_WAIT_VM(8); }                    \
+        else if (nn_ == 7) { PP_WAIT_VM(7); }                    \
+        else if (nn_ == 6) { PP_WAIT_VM(6); }                    \
+        else if (nn_ == 5) { PP_WAIT_VM(5); }                    \
+        else if (nn_ == 4) { PP_WAIT_VM(4); }                    \
+        else { PP_WAIT_VM(0); }                                  \
+    }
+#define PP_BARRIER() \
+    {                \
+        SB();        \
+        __builtin_amdgcn_s_barrier(); \
+        SB();        \
+    }
+
+// Tile = `mr` accumulator rows per group (rows m0 .. m0 + 64*mr), of which rows below `valid_end`
+// belong to this block.
+struct Tile {
+    int64_t m0;
+    int64_t valid_end;
+    int mr;
+};
+
+// activation source of one tile: descriptor at its first row + this lane's byte offsets of the wave's A piece of
+// acc rows 0..3
+struct Rows {
+    i32x4 xrsrc;
+    int av0, av1, av2, av3;
+};
+
+struct Stream {
+    i32x4 wrsrc;
+    Rows cur;                   // tile the requests are for
+    int wv0;                    // and of its first W piece; the others are 64 channel rows (w64 bytes, scalar) apart
+    int w64;
+    unsigned lds_a, lds_w;      // LDS byte address (buffer 0) of this wave's A piece of acc row 0 / its first W piece
+    int row_in_group;           // this lane's row within its group's acc row 0 (A pieces), and the byte offset of
+    int a_chunk;                // the (swizzled) 16-byte chunk it fetches within a 128-byte K-tile slab
+    int u_tile;                 // utterance holding the stream tile's first row, and where the next one starts
+    int64_t off_next;
+    int ws;                     // ring slot (0..2) of the W K-tile the next K-tile to be multiplied uses
+};
+
+// per-lane source offsets of the wave's A pieces for the tile at row t.m0 (see set_tile_rows_impl in
+// tdnn_layer.hip: compact output row p of utterance u reads input rows p + u*span; the utterance
+// boundaries inside the tile are walked with block-uniform values, each lane counts the ones its
+// rows have passed)
+template <bool RAGGED>
+__device__ __forceinline__ void set_rows(const TdnnArgs& a, const Tile& t, int grp, Stream& st, Rows& out) {
+    const int n_last = a.out_map.n_utts - 1;
+    const int64_t t_out = a.out_map.fixed_T - a.out_map.cum;
+    auto next_off = [&](int u) -> int64_t {
+        if (RAGGED) return sload_i64(a.out_map.offsets + __builtin_amdgcn_readfirstlane(u + 1)) - (int64_t)(u + 1) * a.out_map.cum;
+        return (int64_t)(u + 1) * t_out;
+    };
+    while (t.m0 >= st.off_next && st.u_tile < n_last) {
+        st.u_tile = __builtin_amdgcn_readfirstlane(st.u_tile + 1);
+        st.off_next = next_off(st.u_tile);
+    }
+    const int rl = grp * 32 * t.mr + st.row_in_group;     // row of this lane's acc-row-0 piece, relative to m0
+    const int64_t p = t.m0 + rl;
+    int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+    int u = st.u_tile;
+    int64_t nxt = st.off_next;
+    const int64_t t_end = t.m0 + 64 * t.mr;
+    while (nxt < t_end && u < n_last) {
+        c0 += (p >= nxt) ? 1 : 0;
+        c1 += (p + 32 >= nxt) ? 1 : 0;
+        c2 += (p + 64 >= nxt) ? 1 : 0;
+        c3 += (p + 96 >= nxt) ? 1 : 0;
+        u = __builtin_amdgcn_readfirstlane(u + 1);
+        nxt = next_off(u);
+    }
+    const int rb = a.ldx * 2;
+    const int base = rl * rb + st.a_chunk;
+    out.av0 = base + (st.u_tile + c0) * a.span * rb;
+    out.av1 = base + 32 * rb + (st.u_tile + c1) * a.span * rb;
+    out.av2 = base + 64 * rb + (st.u_tile + c2) * a.span * rb;
+    out.av3 = base + 96 * rb + (st.u_tile + c3) * a.span * rb;
+    out.xrsrc = make_srd(static_cast<const char*>(a.X) + t.m0 * (int64_t)a.ldx * 2);
+}
+
+__device__ __forceinline__ void set_rows(const TdnnArgs& a, const Tile& t, int grp, Stream& st, Rows& out) {
+    if (a.out_map.offsets == nullptr) set_rows<false>(a, t, grp, st, out);
+    else set_rows<true>(a, t, grp, st, out);
+}
+
+// Scalar source offset of the activation K-tiles, stepped one K-tile at a time (taps innermost:
+// tap 0, 1, .., then the next 64-channel block): no division in the loop.
+struct KPos {
+    int tap, so;
+};
+__device__ __forceinline__ void kstep(const TdnnArgs& a, KPos& k) {
+    const int tapstep = a.tap_rows * a.ldx * 2;
+    if (k.tap + 1 < a.n_taps) {
+        k.tap += 1;
+        k.so += tapstep;
+    } else {
+        k.so += 128 - k.tap * tapstep;
+        k.tap = 0;
+    }
+}
+
+// --- DMA piece groups of one wave (buffer b_ = parity of the K-tile) -------------------------
+// W: the wave's four pieces (channel rows 8*(wave + 8t) ..+7); A01 / A23: its piece of acc rows 0,1 / 2,(3)
+#define PP_ISSUE_W(slot_, q_)                                                       \
+    {                                                                               \
+        const int so_ = (q_) * kWBytes;              /* K-tile major weights: 32 KiB per K-tile */ \
+        const unsigned d_ = st.lds_w + (slot_) * kWBytes;   /* ring slot 0..2 (scalar) */ \
+        dma16(st.wrsrc, d_, st.wv0, so_);                                           \
+        dma16(st.wrsrc, d_ + 8 * 1024, st.wv0, so_ + st.w64);                       \
+        dma16(st.wrsrc, d_ + 16 * 1024, st.wv0, so_ + 2 * st.w64);                  \
+        dma16(st.wrsrc, d_ + 24 * 1024, st.wv0, so_ + 3 * st.w64);                  \
+    }
+#define PP_ISSUE_A01(b_, so_)                                                       \
+    {                                                                               \
+        dma16(st.cur.xrsrc, st.lds_a + (b_) * kABytes, st.cur.av0, so_);                    \
+        dma16(st.cur.xrsrc, st.lds_a + (b_) * kABytes + kAccRowB, st.cur.av1, so_);         \
+    }
+#define PP_ISSUE_A2(MR_, b_, so_)                                                   \
+    {                                                                               \
+        if ((MR_) > 2) dma16(st.cur.xrsrc, st.lds_a + (b_) * kABytes + 2 * kAccRowB, st.cur.av2, so_);     \
+    }
+
+// A block's first requests, in the K loop's request order -- W(q+2), rows(q+1), W(q+3), rows(q+2), ... -- so that
+// the loop's counted waits hold from the first K-tile: W(0), W(1), rows(0), W(2), rows(1); the loop goes on with
+// W(3) (load 0 of K-tile 0), rows(2) (load 1), ...  W of K-tile x lives in ring slot x % 3.
+__device__ __forceinline__ void issue_head(const TdnnArgs& a, const Stream& st, int mr) {
+    KPos k1 = {0, 0};
+    kstep(a, k1);
+    PP_ISSUE_W(0, 0)
+    PP_ISSUE_W(1, 1)
+    PP_ISSUE_A01(0, 0)
+    PP_ISSUE_A2(mr, 0, 0)
+    PP_ISSUE_W(2, 2)
+    PP_ISSUE_A01(1, k1.so)
+    PP_ISSUE_A2(mr, 1, k1.so)
+}
+
+struct Lane {
+    int h, r;
+    int rd;          // r*128: row part of every fragment read
+    int k0, k1, k2, k3;   // swizzled byte offset of this lane's 16-byte chunk for k-steps 0..3
+    unsigned a_rd;   // LDS byte offset (buffer 0) of this wave's group's acc row 0, + rd
+    unsigned w_rd;   // LDS byte offset (buffer 0) of this wave's channel column 0, + rd
+    int wave, grp, wc;
+};
+
+#define PP_RD(dst_, off_) if constexpr (!PP_KNOCK_RD) dst_ = *reinterpret_cast<const float4*>(smem + (off_));
+#define PP_RDW(dst_, off_) if constexpr (!PP_KNOCK_RDW) PP_RD(dst_, off_)
+// one W fragment: register set S_ (a / b: the K-tile being multiplied and the next one alternate), column j_,
+// k-step s_, from buffer b_
+#define PP_RW(S_, j_, s_, base_) PP_RDW(w##S_##j_##_##s_, (base_) + (j_) * kAccRowB + ln.k##s_)
+// one MFMA: accumulator (row i_, column j_), A fragment set f_, k-step s_, W register set S_.  Store variant: the
+// weights are the MFMA A operand (channels -> accumulator registers); pooling variant: the activations are.
+#define PP_MF(S_, i_, j_, f_, s_)                                                                                  \
+    if constexpr (POOL)                                                                                            \
+        acc##i_##j_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af##f_##_##s_),           \
+                                                              __builtin_bit_cast(bf16x8, w##S_##j_##_##s_), acc##i_##j_, 0, 0, 0); \
+    else                                                                                                           \
+        acc##i_##j_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w##S_##j_##_##s_),        \
+                                                              __builtin_bit_cast(bf16x8, af##f_##_##s_), acc##i_##j_, 0, 0, 0);
+
+// One MFMA step (k-step s_) of acc rows 0, 1 (fragment sets of the same number) x both columns
+#define PP_MF4(S_, s_) PP_MF(S_, 0, 0, 0, s_) PP_MF(S_, 0, 1, 0, s_) PP_MF(S_, 1, 0, 1, s_) PP_MF(S_, 1, 1, 1, s_)
+// a single MFMA (acc row i_, column j_, k-step s_; fragment set = row), to be followed by ONE LDS read: a
+// ds_read_b128 holds the wave's issue for ~30 cycles (stamps, profiles/diag/pp_stamps.py), which is free
+// exactly when an MFMA of this wave is executing (32 cycles) -- so reads and MFMAs alternate one to one
+#define PP_M1(S_, i_, j_, s_) PP_MF(S_, i_, j_, i_, s_) SB();
+// one activation fragment read: acc row i_ (= fragment set i_), k-step s_, from buffer b_
+#define PP_RA(i_, s_, b_) if constexpr (!PP_KNOCK_RDA) PP_RD(af##i_##_##s_, ln.a_rd + (b_) * kABytes + (i_) * kAccRowB + ln.k##s_)
+
+// One K-tile held in LDS buffer b_ (odd_ = its parity); WC_ / WN_ = the register sets (a, b) of its weight
+// fragments and of the next K-tile's.  k2.so / wq = activation source offset and index of the K-tile requested
+// now, two K-tiles ahead; mr_req = height of the tile it belongs to.  The request stream does not stop at the
+// end of a tile: in a tile's last two K-tiles ("last") the requests are the NEXT tile's K-tiles 0 and 1 (the
+// stream state was switched to that tile just before), so a tile starts with its first K-tiles in LDS.  Only a
+// block's last tile requests nothing there.
+//   load 0:  request W of K-tile q+2 (4 pieces)
+//   mfma 0:  MR=3: acc rows 0,1, k-steps 0-2 (12 MFMAs), behind them the 4 fragment reads of acc row 2 and the
+//            8 W fragment reads of K-tile q+1;  MR=2: acc rows 0,1, k-steps 0,1 (8) with the 8 W reads
+//   load 1:  request acc rows 0,1,(2) of K-tile q+2 (2-3 pieces)
+//   mfma 1:  MR=3: acc rows 0,1 k-step 3, then acc row 2 (12) with the 8 fragment reads of acc rows 0,1 of
+//            K-tile q+1 behind the acc row 2 MFMAs;  MR=2: k-steps 2,3 (8) with those 8 reads, each one behind
+//            the last MFMA that uses the register it overwrites
+// NO fragment is read in a load segment (round 2's first version read the 8 W fragments there: ~300 cycles of
+// a 650-cycle load segment, against MFMA segments of 430-490 -- the other group's MFMAs waited at the barrier).
+// A load segment is now the 2-4 DMA instructions and the counted wait; the W fragments cost 32 more registers,
+// which is why tiles are 3 or 2 accumulator rows high, not 4.  W is read in mfma 0 ONLY: the other group runs
+// one segment behind, and W of K-tile q+2 overwrites W of K-tile q at this group's load 0 -- by then the other
+// group is in its mfma 1 of K-tile q-1 and must be done with W of K-tile q.
+// The two segments of a wave are equally long, so the SIMD partner's load segments have the same time to
+// hide in.  Every segment ends with lgkmcnt(0) before its barrier (a slot may be refilled in any later segment).
+// Counted vmcnt at the end of a load segment.  Request order per wave: W(q) [4] | rows 0,1 (q) [2], row 2 (q)
+// [a = MR - 2] | W(q+1) ...; a1, a2 = a of the tiles K-tiles q+1, q+2 belong to:
+//   load 0 must have W of K-tile q+1 (everything older with it, row 2 of K-tile q included):
+//          younger = rows(q+1) [2 + a1] + W(q+2) [4]
+//   load 1 must have rows 0,1 of K-tile q+1:  younger = a1 + W(q+2) [4] + rows(q+2) [2 + a2]
+// -- never a drain, except where nothing further was requested.  (The epilogue's stores sit in the same queue:
+// the first waits of the next tile then wait for a few entries more than they need to, long completed.)
+#define PP_KTILE(b_, odd_, WC_, WN_)                                                \
+    {                                                                               \
+        SB();                                                                       \
+        if (!PP_KNOCK_DMA) PP_ISSUE_W(ws, wq)          /* W of K-tile q+3 -> the slot of K-tile q */ \
+        const unsigned wrd = ln.w_rd + (ws == 2 ? 0 : ws + 1) * kWBytes;   /* slot of K-tile q+1 */ \
+        SB();                                                                       \
+        PP_STAMP(0)                                                                 \
+        if (!(last && (odd_))) { if (MR == 3) { PP_WAIT_VM(11); } else { PP_WAIT_VM(10); } } \
+        else { PP_WAIT_VM_RT(req ? mr_req + 8 : 8) }                                \
+        PP_STAMP(1)                                                                 \
+        PP_BARRIER()                                                                \
+        PP_STAMP(2)                                                                 \
+        __builtin_amdgcn_s_setprio(1);                                              \
+        if constexpr (MR == 3) {                                                    \
+            PP_M1(WC_, 0, 0, 0) PP_RA(2, 0, b_) SB(); PP_M1(WC_, 0, 1, 0) PP_RA(2, 1, b_) SB(); \
+            PP_M1(WC_, 1, 0, 0) PP_RA(2, 2, b_) SB(); PP_M1(WC_, 1, 1, 0) PP_RA(2, 3, b_) SB(); \
+            PP_M1(WC_, 0, 0, 1) PP_RW(WN_, 0, 0, wrd) SB(); PP_M1(WC_, 0, 1, 1) PP_RW(WN_, 0, 1, wrd) SB(); \
+            PP_M1(WC_, 1, 0, 1) PP_RW(WN_, 0, 2, wrd) SB(); PP_M1(WC_, 1, 1, 1) PP_RW(WN_, 0, 3, wrd) SB(); \
+            PP_M1(WC_, 0, 0, 2) PP_RW(WN_, 1, 0, wrd) SB(); PP_M1(WC_, 0, 1, 2) PP_RW(WN_, 1, 1, wrd) SB(); \
+            PP_M1(WC_, 1, 0, 2) PP_RW(WN_, 1, 2, wrd) SB(); PP_M1(WC_, 1, 1, 2) PP_RW(WN_, 1, 3, wrd) SB(); \
+        } else {                                                                    \
+            PP_M1(WC_, 0, 0, 0) PP_RW(WN_, 0, 0, wrd) SB(); PP_M1(WC_, 0, 1, 0) PP_RW(WN_, 0, 1, wrd) SB(); \
+            PP_M1(WC_, 1, 0, 0) PP_RW(WN_, 0, 2, wrd) SB(); PP_M1(WC_, 1, 1, 0) PP_RW(WN_, 0, 3, wrd) SB(); \
+            PP_M1(WC_, 0, 0, 1) PP_RW(WN_, 1, 0, wrd) SB(); PP_M1(WC_, 0, 1, 1) PP_RW(WN_, 1, 1, wrd) SB(); \
+            PP_M1(WC_, 1, 0, 1) PP_RW(WN_, 1, 2, wrd) SB(); PP_M1(WC_, 1, 1, 1) PP_RW(WN_, 1, 3, wrd) SB(); \
+        }                                                                           \
+        __builtin_amdgcn_s_setprio(0);                                              \
+        PP_WAIT_LGKM();                                                             \
+        PP_STAMP(3)                                                                 \
+        PP_BARRIER()                                                                \
+        PP_STAMP(4)                                                                 \
+        if (req && !PP_KNOCK_DMA) {                                                 \
+            PP_ISSUE_A01(b_, k2.so)                                                 \
+            PP_ISSUE_A2(mr_req, b_, k2.so)                                          \
+        }                                                                           \
+        SB();                                                                       \
+        PP_STAMP(6)                                                                 \
+        if (!last) { if (MR == 3) { PP_WAIT_VM(8); } else { PP_WAIT_VM(6); } }      \
+        else if (!(odd_)) { PP_WAIT_VM_RT(req ? MR + mr_req + 2 : MR + 2) }         \
+        else { PP_WAIT_VM_RT(req ? 2 * mr_req + 2 : 4) }                            \
+        PP_STAMP(7)                                                                 \
+        PP_BARRIER()                                                                \
+        PP_STAMP(8)                                                                 \
+        __builtin_amdgcn_s_setprio(1);                                              \
+        /* (after a block's last K-tile the reads below fetch stale bytes that nobody uses: cheaper than a branch */ \
+        /*  around the MFMAs, which made hipcc keep two register assignments alive and spill) */ \
+        if constexpr (MR == 3) {                                                    \
+            PP_MF4(WC_, 3) SB();                                                    \
+            PP_M1(WC_, 2, 0, 0) PP_RA(0, 0, (b_) ^ 1) SB(); PP_M1(WC_, 2, 1, 0) PP_RA(0, 1, (b_) ^ 1) SB(); \
+            PP_M1(WC_, 2, 0, 1) PP_RA(0, 2, (b_) ^ 1) SB(); PP_M1(WC_, 2, 1, 1) PP_RA(0, 3, (b_) ^ 1) SB(); \
+            PP_M1(WC_, 2, 0, 2) PP_RA(1, 0, (b_) ^ 1) SB(); PP_M1(WC_, 2, 1, 2) PP_RA(1, 1, (b_) ^ 1) SB(); \
+            PP_M1(WC_, 2, 0, 3) PP_RA(1, 2, (b_) ^ 1) SB(); PP_M1(WC_, 2, 1, 3) PP_RA(1, 3, (b_) ^ 1) SB(); \
+        } else {                                                                    \
+            PP_M1(WC_, 0, 0, 2) PP_RA(0, 0, (b_) ^ 1) SB(); PP_M1(WC_, 0, 1, 2) PP_RA(0, 1, (b_) ^ 1) SB(); \
+            PP_M1(WC_, 1, 0, 2) PP_RA(1, 0, (b_) ^ 1) SB(); PP_M1(WC_, 1, 1, 2) PP_RA(1, 1, (b_) ^ 1) SB(); \
+            PP_M1(WC_, 0, 0, 3) PP_RA(0, 2, (b_) ^ 1) SB(); PP_M1(WC_, 0, 1, 3) PP_RA(0, 3, (b_) ^ 1) SB(); \
+            PP_M1(WC_, 1, 0, 3) PP_RA(1, 2, (b_) ^ 1) SB(); PP_M1(WC_, 1, 1, 3) PP_RA(1, 3, (b_) ^ 1) SB(); \
+        }                                                                           \
+        __builtin_amdgcn_s_setprio(0);                                              \
+        PP_WAIT_LGKM();                                                             \
+        PP_STAMP(9)                                                                 \
+        PP_BARRIER()                                                                \
+        PP_STAMP(10)                                                                \
+        kstep(a, k2);                                                               \
+        wq = wq + 1 == nk ? 0 : wq + 1;                                             \
+        ws = ws == 2 ? 0 : ws + 1;                                                  \
+    }
+
+// Fused statistics pooling for the pooling variant (main.py:59-63), frames in the accumulator registers and
+// the channel on the lane.  The epilogue runs in the open here (both waves of a SIMD are in it at the same
+// time, the matrix pipe idles), so it is as short as the arithmetic allows: per (32-frame group, utterance)
+// and channel the RAW sums S1 = sum r, S2 = sum r^2 of r = relu(z + bias) over the utterance's frames in the
+// group -- one v_max, one add and one fma per value.  Scale and shift of the folded BatchNorm are applied
+// by pool_finalize (mean = shift + scale*S1/n, std = |scale|*sqrt((S2 - S1^2/n)/(n-1)) with the totals and
+// the difference taken in fp64); r >= 0 keeps the cancellation in S2 - S1^2/n mild (relative error of the
+// variance ~1e-7*(1 + mean^2/var)), far inside this bf16 path's 1e-2 bar.
+// v0 / v1: the accumulators of this wave's two 32-channel columns for the group at compact row row_g
+// (bias already inside: the accumulators start at it).
+// Returns true when the group lay inside one utterance.
+// RAGGED is a template parameter and the utterance index is kept provably wave-uniform on purpose: with
+// a run-time "offsets ? load : multiply" hipcc emitted VECTOR loads of the offsets followed by
+// s_waitcnt vmcnt(0) -- on the fixed-length path too -- and every one of those waits drained the DMA
+// queue (the next tile's first K-tiles) in the middle of the epilogue.
+template <bool RAGGED>
+__device__ __forceinline__ int64_t first_row(const RowMap& m, int u) {
+    u = __builtin_amdgcn_readfirstlane(u);
+    if (RAGGED) return sload_i64(m.offsets + u) - (int64_t)u * m.cum;
+    return (int64_t)u * (m.fixed_T - m.cum);
+}
+template <bool RAGGED>
+__device__ __forceinline__ bool pool_raw_pair(const TdnnArgs& a, const f32x16& v0, const f32x16& v1, int64_t row_g,
+                                              int h, int col0, PoolCur& pc) {
+    const RowMap& m = a.out_map;
+    while (pc.end <= row_g && pc.u < m.n_utts - 1) {
+        pc.u = __builtin_amdgcn_readfirstlane(pc.u + 1);
+        pc.end = first_row<RAGGED>(m, pc.u + 1);
+    }
+    const int64_t grp = row_g >> 5;
+    const int ld = a.ldy;
+    const __amdgpu_buffer_rsrc_t prs = make_rsrc(a.pool_part);
+    if (pc.end >= row_g + 32) {               // the whole group belongs to utterance pc.u
+        // two values per instruction where the ISA has one (v_pk_add_f32 / v_pk_fma_f32; the max has none)
+        f32x2 p1a = {0.f, 0.f}, p2a = {0.f, 0.f}, p1b = {0.f, 0.f}, p2b = {0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 16; e += 2) {
+            const f32x2 ra = {fmaxf(v0[e], 0.f), fmaxf(v0[e + 1], 0.f)};
+            const f32x2 rb = {fmaxf(v1[e], 0.f), fmaxf(v1[e + 1], 0.f)};
+            p1a += ra;
+            p2a = __builtin_elementwise_fma(ra, ra, p2a);
+            p1b += rb;
+            p2b = __builtin_elementwise_fma(rb, rb, p2b);
+        }
+        const float s1a = add_halves(p1a.x + p1a.y), s2a = add_halves(p2a.x + p2a.y);
+        const float s1b = add_halves(p1b.x + p1b.y), s2b = add_halves(p2b.x + p2b.y);
+        store_partial(prs, ld, grp + pc.u, h, col0, s1a, s2a);
+        store_partial(prs, ld, grp + pc.u, h, col0 + 32, s1b, s2b);
+        return true;
+    }
+    for (int u = pc.u; u < m.n_utts; u = __builtin_amdgcn_readfirstlane(u + 1)) {   // the group straddles utterances
+        const int64_t off = first_row<RAGGED>(m, u);
+        if (off >= row_g + 32) break;
+        const int64_t end = first_row<RAGGED>(m, u + 1);
+        const int64_t lo_r = off > row_g ? off : row_g;
+        const int64_t hi_r = end < row_g + 32 ? end : row_g + 32;
+        if (hi_r <= lo_r) continue;
+        const int lo_l = (int)(lo_r - row_g), hi_l = (int)(hi_r - row_g);
+        const unsigned below_hi = hi_l >= 32 ? 0xffffffffu : ((1u << hi_l) - 1u);
+        const unsigned lm = (below_hi & ~((1u << lo_l) - 1u)) >> (4 * h);   // this lane's rows: bits (e&3) + 8*(e>>2)
+        float s1a = 0.f, s2a = 0.f, s1b = 0.f, s2b = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const bool in = (lm >> ((e & 3) + 8 * (e >> 2))) & 1u;      // a SELECT: rows outside may hold anything
+            const float ra = in ? fmaxf(v0[e], 0.f) : 0.f, rb = in ? fmaxf(v1[e], 0.f) : 0.f;
+            s1a += ra;
+            s2a = fmaf(ra, ra, s2a);
+            s1b += rb;
+            s2b = fmaf(rb, rb, s2b);
+        }
+        s1a = add_halves(s1a);
+        s2a = add_halves(s2a);
+        s1b = add_halves(s1b);
+        s2b = add_halves(s2b);
+        store_partial(prs, ld, grp + u, h, col0, s1a, s2a);
+        store_partial(prs, ld, grp + u, h, col0 + 32, s1b, s2b);
+    }
+    return false;
+}
+
+// One tile: K loop, request of the next tile's first K-tiles, epilogue.
+template <int MR, bool POOL>
+__device__ __forceinline__ void process_tile(const TdnnArgs& a, char* smem, Stream& st, const Lane& ln,
+                                             const Tile& t, const Tile& nxt, bool has_next, bool first, int n0, int nk,
+                                             PoolCur& pc, float bi0, float bi1) {
+    // source rows of the NEXT tile (its first K-tiles are requested during this tile's last two): worked out
+    // here, before the accumulators exist, and parked in four registers
+    Rows rows_next = st.cur;
+    if (has_next) set_rows(a, nxt, ln.grp, st, rows_next);
+    // the accumulators start at the bias: of their lane's channel (pooling variant: channel on the lane), or of
+    // each register's channel (store variant: 16 channels per lane and column, from the LDS copy)
+    f32x16 acc00, acc01, acc10, acc11, acc20, acc21;
+    if constexpr (POOL) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            acc00[e] = bi0; acc01[e] = bi1; acc10[e] = bi0; acc11[e] = bi1;
+            acc20[e] = bi0; acc21[e] = bi1;
+        }
+    } else {
+        const char* cb = smem + kConstOff + (ln.wc * 64 + 4 * ln.h) * 4;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const float4 b0 = *reinterpret_cast<const float4*>(cb + gq * 32);
+            const float4 b1 = *reinterpret_cast<const float4*>(cb + 128 + gq * 32);
+            acc00[4 * gq] = b0.x; acc00[4 * gq + 1] = b0.y; acc00[4 * gq + 2] = b0.z; acc00[4 * gq + 3] = b0.w;
+            acc01[4 * gq] = b1.x; acc01[4 * gq + 1] = b1.y; acc01[4 * gq + 2] = b1.z; acc01[4 * gq + 3] = b1.w;
+        }
+        acc10 = acc00; acc20 = acc00;
+        acc11 = acc01; acc21 = acc01;
+    }
+    // W fragments, two sets: K-tiles of buffer 0 multiply from set a while set b is filled, and vice versa
+    float4 wa0_0, wa0_1, wa0_2, wa0_3, wa1_0, wa1_1, wa1_2, wa1_3;
+    float4 wb0_0, wb0_1, wb0_2, wb0_3, wb1_0, wb1_1, wb1_2, wb1_3;
+    float4 af0_0, af0_1, af0_2, af0_3, af1_0, af1_1, af1_2, af1_3;     // acc rows 0,1 (read during the previous mfma 1)
+    float4 af2_0, af2_1, af2_2, af2_3;                                 // acc row 2 (read during mfma 0)
+#ifdef XVEC_DIAG
+    unsigned long long dsum[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long dprev, dstart;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dstart)::"memory");
+#endif
+
+#ifdef XVEC_KNOCK
+    if (PP_KNOCK_RD || PP_KNOCK_RDW || PP_KNOCK_RDA) {
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        wa0_0 = wa0_1 = wa0_2 = wa0_3 = wa1_0 = wa1_1 = wa1_2 = wa1_3 = z;
+        wb0_0 = wb0_1 = wb0_2 = wb0_3 = wb1_0 = wb1_1 = wb1_2 = wb1_3 = z;
+        af0_0 = af0_1 = af0_2 = af0_3 = af1_0 = af1_1 = af1_2 = af1_3 = z;
+        af2_0 = af2_1 = af2_2 = af2_3 = z;
+    }
+#endif
+    // A block's first tile waits for its first K-tile (requested by the kernel prologue; its pieces are older
+    // than the MR+4 of K-tile 1); later tiles find it in LDS, confirmed by the previous tile's last K-tiles.
+    if (first) {
+        if (MR == 3) { PP_WAIT_VM(7); } else { PP_WAIT_VM(6); }
+        PP_BARRIER()
+    }
+    // acc rows 0,1 and the W fragments of K-tile 0: the only fragments read outside an MFMA segment (the previous
+    // tile's last MFMA segments fetched them too, but keeping them in registers across the epilogue costs it 64
+    // VGPRs)
+    PP_RA(0, 0, 0) PP_RA(0, 1, 0) PP_RA(0, 2, 0) PP_RA(0, 3, 0)
+    PP_RA(1, 0, 0) PP_RA(1, 1, 0) PP_RA(1, 2, 0) PP_RA(1, 3, 0)
+    int ws = st.ws;
+    {
+        const unsigned w0 = ln.w_rd + ws * kWBytes;
+        PP_RW(a, 0, 0, w0) PP_RW(a, 0, 1, w0) PP_RW(a, 0, 2, w0) PP_RW(a, 0, 3, w0)
+        PP_RW(a, 1, 0, w0) PP_RW(a, 1, 1, w0) PP_RW(a, 1, 2, w0) PP_RW(a, 1, 3, w0)
+    }
+    PP_WAIT_LGKM();
+    // Their slots are the first ones the loop refills (load 0 of K-tile 0 requests K-tile 2 into them), and the
+    // waves of a group leave the epilogue at different times: every wave must have read them before any wave
+    // may request.  (Deferring that one request instead costs a branch in the loop, and with it hipcc's
+    // register assignment: 160 spilled registers.)
+    PP_BARRIER()
+    if (ln.grp == 1) PP_BARRIER()          // ping-pong: the second group runs one barrier behind
+#ifdef XVEC_DIAG
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dprev)::"memory");
+    dsum[12] += dprev - dstart;            // head wait
+#endif
+    KPos k2 = {0, 0};                       // K-tile requested now (two ahead of the one computed), its W index,
+    kstep(a, k2);                           // the height of its tile, and whether there is anything to request
+    kstep(a, k2);
+    int wq = 3;                             // W runs three K-tiles ahead and simply wraps round into the next tile
+    int mr_req = MR;
+    bool req = true;
+    for (int q = 0; q < nk; q += 2) {
+        const bool last = q + 2 >= nk;
+        if (last) {                         // from here on the requests are the next tile's K-tiles 0 and 1
+            req = has_next;                 // (a peeled copy of the last pair made hipcc spill ~250 registers)
+            if (has_next) {
+                st.cur = rows_next;
+                mr_req = nxt.mr;
+                k2.tap = 0;
+                k2.so = 0;
+            }
+        }
+        PP_KTILE(0, false, a, b)
+        PP_KTILE(1, true, b, a)
+    }
+    st.ws = ws;
+    if (ln.grp == 0) PP_BARRIER()
+    PP_STAMP(13)                            // tail barrier
+    PP_STAMP(5)
+
+    const int64_t row0 = t.m0 + ln.grp * 32 * MR;
+    if constexpr (PP_KNOCK_EPI) {
+        asm volatile("" ::"v"(acc00), "v"(acc01), "v"(acc10), "v"(acc11), "v"(acc20), "v"(acc21));
+    } else if constexpr (!POOL) {
+        const __amdgpu_buffer_rsrc_t yrsrc = make_rsrc(static_cast<char*>(a.Y) + (t.m0 * (int64_t)a.ldy + n0) * 2);
+        const int y_voff = (ln.r * a.ldy + ln.wc * 64 + 8 * ln.h) * 2;
+        const char* cst = smem + kConstOff + (ln.wc * 64 + 4 * ln.h) * 4;
+#define PP_STORE(i_, j_)                                                                               \
+        if constexpr (MR > i_) {                                                                       \
+            if (row0 + 32 * i_ < t.valid_end)                                                             \
+                store_acc(acc##i_##j_, sc, sh, yrsrc, y_voff, (ln.grp * 32 * MR + 32 * i_) * a.ldy * 2 + 64 * j_); \
+        }
+        {
+            float4 sc[4], sh[4];
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                sc[gq] = *reinterpret_cast<const float4*>(cst + 1024 + gq * 32);
+                sh[gq] = *reinterpret_cast<const float4*>(cst + 2048 + gq * 32);
+            }
+            PP_STORE(0, 0) PP_STORE(1, 0) PP_STORE(2, 0)
+        }
+        {
+            float4 sc[4], sh[4];
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                sc[gq] = *reinterpret_cast<const float4*>(cst + 128 + 1024 + gq * 32);
+                sh[gq] = *reinterpret_cast<const float4*>(cst + 128 + 2048 + gq * 32);
+            }
+            PP_STORE(0, 1) PP_STORE(1, 1) PP_STORE(2, 1)
+        }
+#undef PP_STORE
+    } else {
+        const int col0 = n0 + ln.wc * 64 + ln.r;
+#define PP_POOL(RG_, i_)                                                                               \
+        if constexpr (MR > i_) {                                                                       \
+            if (row0 + 32 * i_ < t.valid_end)                                                             \
+                pool_raw_pair<RG_>(a, acc##i_##0, acc##i_##1, row0 + 32 * i_, ln.h, col0, pc);            \
+        }
+        if (a.out_map.offsets == nullptr) {
+            PP_POOL(false, 0) PP_POOL(false, 1) PP_POOL(false, 2)
+        } else {
+            PP_POOL(true, 0) PP_POOL(true, 1) PP_POOL(true, 2)
+        }
+#undef PP_POOL
+    }
+#ifdef XVEC_DIAG
+    {
+        unsigned long long dend;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dend)::"memory");
+        dsum[11] += dend - dprev;          // epilogue + second K-tile of the next tile
+        dsum[14] += 1;
+        dsum[15] += (unsigned long long)MR;
+        if ((ln.wave & 3) == 0 && ln.r == 0 && ln.h == 0 && blockIdx.x < 512) {
+            _Pragma("unroll") for (int k = 0; k < 16; ++k) g_pp_diag[(POOL ? 512 * 32 : 0) + blockIdx.x * 32 + ln.grp * 16 + k] += dsum[k];
+        }
+    }
+#endif
+}
+
+template <bool POOL>
+__global__ __launch_bounds__(kThreads, 2) void tdnn_pp_kernel(const TdnnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int jcol = lid % a.n_tiles;                   // 256-channel column
+    const int prange = lid / a.n_tiles;
+    const int64_t u_begin = a.groups_total * (int64_t)prange / a.blocks_per_col;     // 64-frame units
+    const int64_t u_end = a.groups_total * (int64_t)(prange + 1) / a.blocks_per_col;
+    const int n0 = jcol * 256;
+    const int nk = a.n_taps * a.cpt;                    // K-tiles of 64 (even)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    Lane ln;
+    ln.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    ln.grp = ln.wave >> 2;
+    ln.wc = ln.wave & 3;
+    ln.h = lane >> 5;
+    ln.r = lane & 31;
+    ln.rd = ln.r * kRowB;
+    {
+        const int sw = (ln.r >> 1) & 7;
+        ln.k0 = ((0 + ln.h) ^ sw) << 4;
+        ln.k1 = ((2 + ln.h) ^ sw) << 4;
+        ln.k2 = ((4 + ln.h) ^ sw) << 4;
+        ln.k3 = ((6 + ln.h) ^ sw) << 4;
+    }
+    ln.a_rd = ln.grp * 3 * kAccRowB + ln.rd;
+    ln.w_rd = kWOff + ln.wc * 2 * kAccRowB + ln.rd;
+
+    // per-channel constants of the block's column -> LDS (store variant reads them per register)
+    if (tid < 192) {
+        const int arr = tid >> 6, c4 = (tid & 63) * 4;
+        const float* src = arr == 0 ? a.bias : arr == 1 ? a.scale : a.shift;
+        *reinterpret_cast<float4*>(smem + kConstOff + arr * 1024 + c4 * 4) = *reinterpret_cast<const float4*>(src + n0 + c4);
+    }
+    float bi0 = 0.f, bi1 = 0.f;
+    if (POOL) {
+        const int c = n0 + ln.wc * 64 + ln.r;
+        bi0 = a.bias[c];
+        bi1 = a.bias[c + 32];
+    }
+
+    // DMA map of this wave: piece row = lane >> 3 (8 rows per piece), LDS position lane & 7 holds the
+    // source chunk (lane & 7) ^ swizzle(row), swizzle = (row >> 1) & 7 of the row's index in its 32-row block
+    Stream st;
+    const int prow = lane >> 3, ppos = lane & 7;
+    {
+        const int rr = ln.wc * 8 + prow;                                  // A: row within the 32-frame acc row
+        st.row_in_group = rr;
+        st.a_chunk = (ppos ^ ((rr >> 1) & 7)) * 16;
+        st.lds_a = (unsigned)(unsigned long long)(lds_ptr)(smem) + ln.grp * 3 * kAccRowB + ln.wc * 1024;
+        const int wr = ln.wave * 8 + prow;                                // W: channel row of piece t = wr + 64*t
+        const int w_chunk = (ppos ^ ((wr >> 1) & 7)) * 16;                // ((wr + 64t) >> 1) & 7 is the same for every t
+        st.lds_w = (unsigned)(unsigned long long)(lds_ptr)(smem) + kWOff + ln.wave * 1024;
+        st.ws = 0;
+        st.wv0 = wr * kRowB + w_chunk;                                    // K-tile major: rows 128 B apart
+        st.w64 = 64 * kRowB;
+        st.wrsrc = make_srd(static_cast<const char*>(a.W) + (int64_t)jcol * nk * kWBytes);
+        st.cur.av0 = st.cur.av1 = st.cur.av2 = st.cur.av3 = 0;
+        st.u_tile = __builtin_amdgcn_readfirstlane(utt_of_row(a.out_map, u_begin * 64));
+        st.off_next = row_off(a.out_map, st.u_tile + 1);
+        st.cur.xrsrc = st.wrsrc;
+        PoolCur pc;
+        pc.u = 0;
+        pc.end = 0;
+
+        // tiles of this block: n units cut into tiles of 3 units and at most two of 2 (n = 1: one tile of 2 whose
+        // second unit lies past the range and is masked)
+        const int n = (int)(u_end - u_begin);
+        if (n <= 0) return;
+        const int n2 = n % 3 == 0 ? 0 : n % 3 == 2 ? 1 : (n >= 4 ? 2 : 1);
+        const int n3 = n >= 2 * n2 ? (n - 2 * n2) / 3 : 0;
+        const int nt = n3 + n2;
+        const int64_t range_end = u_end * 64;
+
+        auto tile_at = [&](int idx, int64_t m0) {
+            Tile t;
+            t.m0 = m0;
+            t.mr = idx < n3 ? 3 : 2;
+            t.valid_end = range_end;
+            return t;
+        };
+        Tile cur = tile_at(0, u_begin * 64);
+        if (POOL) pc = pool_cursor(a, cur.m0 + ln.grp * 32 * cur.mr);
+        set_rows(a, cur, ln.grp, st, st.cur);
+        __syncthreads();                                   // constants visible; nobody reads LDS buffers yet
+        issue_head(a, st, cur.mr);
+        for (int idx = 0; idx < nt; ++idx) {
+            const bool has_next = idx + 1 < nt;
+            Tile nxt = cur;
+            if (has_next) nxt = tile_at(idx + 1, cur.m0 + 64 * cur.mr);
+            if (cur.mr == 3)
+                process_tile<3, POOL>(a, smem, st, ln, cur, nxt, has_next, idx == 0, n0, nk, pc, bi0, bi1);
+            else
+                process_tile<2, POOL>(a, smem, st, ln, cur, nxt, has_next, idx == 0, n0, nk, pc, bi0, bi1);
+            cur = nxt;
+        }
+        // the weight requests wrapped round past the block's last tile: nothing may still be writing LDS at exit
+        PP_WAIT_VM(0);
+    }
+}
+
+}  // namespace pp
+
+#ifdef XVEC_DIAG
+extern "C" int xvec_pp_diag_read(unsigned long long* host, int n_words, int reset) {
+    hipError_t e = hipMemcpyFromSymbol(host, HIP_SYMBOL(pp::g_pp_diag), (size_t)n_words * 8);
+    if (e == hipSuccess && reset) e = hipMemset(nullptr, 0, 0);
+    if (reset) {
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(pp::g_pp_diag)) == hipSuccess) (void)hipMemset(p, 0, sizeof(unsigned long long) * 2 * 512 * 32);
+    }
+    return (int)e;
+}
+#endif
+
+hipError_t launch_tdnn_pp(const TdnnArgs& a, bool pool, hipStream_t s) {
+    if (a.groups_total <= 0 || a.blocks_per_col <= 0 || a.blocks_per_col > a.groups_total || (a.cpt & 1) ||
+        a.n_tiles <= 0 || a.n_taps * a.cpt < 4)
+        return hipErrorInvalidValue;
+    const int grid = a.blocks_per_col * a.n_tiles;
+    if (pool) {
+        static LdsOptIn opt;
+        if (hipError_t e = opt.ensure(reinterpret_cast<const void*>(pp::tdnn_pp_kernel<true>), pp::kLdsBytes); e != hipSuccess)
+            return e;
+        pp::tdnn_pp_kernel<true><<<dim3(grid), dim3(pp::kThreads), pp::kLdsBytes, s>>>(a);
+    } else {
+        static LdsOptIn opt;
+        if (hipError_t e = opt.ensure(reinterpret_cast<const void*>(pp::tdnn_pp_kernel<false>), pp::kLdsBytes); e != hipSuccess)
+            return e;
+        pp::tdnn_pp_kernel<false><<<dim3(grid), dim3(pp::kThreads), pp::kLdsBytes, s>>>(a);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace xvec

@@ -358,9 +358,10 @@ def main():
         traffic, traffic_src = None, None
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-            tj = tj[args.dtype]                             # one section per arithmetic (bf16x3: no PMC pass yet)
+            tj = tj[args.dtype]                             # one section per arithmetic
             key = {"fp32": "tdnn_kernel<0, false, true, false, false, false>",
-                   "bf16": "pp::tdnn_pp_kernel<false>" if pp16 else "tdnn_kernel<0, false, true, true, true, false>"}[args.dtype]
+                   "bf16": "pp::tdnn_pp_kernel<false>" if pp16 else "tdnn_kernel<0, false, true, true, true, false>",
+                   "bf16x3": "tdnn_kernel<0, false, true, true, true, true>"}[args.dtype]
             traffic, traffic_src = tj[key]["hbm_bytes_per_launch"], tj["source"]
         except (OSError, KeyError, ValueError, StopIteration):
             pass

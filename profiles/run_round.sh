@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round profile set (run on the GPU box via gpurun):  bash profiles/run_round.sh <tag>
-#   kernel-trace stats of the default bench line (fp32 + its secondary legs) and of --dtype bf16,
+#   kernel-trace stats of the default bench line (fp32 + its secondary legs), of --dtype bf16 and of --dtype bf16x3,
 #   FETCH_SIZE / WRITE_SIZE passes for both, utilisation counters for both.  Output: gpurun_out/<tag>/
 tag=${1:-r02}
 cd /tmp && export TMPDIR=/tmp
@@ -11,7 +11,8 @@ python3 bench.py --steps 50 --warmup 10 > $out/bench_fp32.json 2> $out/bench_fp3
 python3 bench.py --steps 50 --warmup 10 --dtype bf16 --cpu-budget 0 > $out/bench_bf16.json 2> $out/bench_bf16.err; echo "bench bf16 exit $?"
 python3 bench.py --steps 20 --warmup 5 --workload ragged --cpu-budget 0 > $out/bench_ragged.json 2> $out/bench_ragged.err; echo "bench ragged exit $?"
 python3 bench.py --steps 20 --warmup 5 --workload ragged --dtype bf16 --cpu-budget 0 > $out/bench_ragged_bf16.json 2> $out/bench_ragged_bf16.err; echo "bench ragged bf16 exit $?"
-for dt in fp32 bf16; do
+python3 bench.py --steps 50 --warmup 10 --dtype bf16x3 --cpu-budget 0 > $out/bench_bf16x3.json 2> $out/bench_bf16x3.err; echo "bench bf16x3 exit $?"
+for dt in fp32 bf16 bf16x3; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_$dt -o $dt -- python3 bench.py --steps 20 --warmup 5 --cpu-budget 0 --no-secondary --dtype $dt > $out/stats_$dt.log 2>&1
   echo "stats $dt exit $?"
   i=0
@@ -25,5 +26,5 @@ for dt in fp32 bf16; do
   done
   python3 profiles/summarize_pmc.py $out/pmc_$dt > $out/pmc_summary_$dt.txt 2>&1
 done
-python3 profiles/make_traffic.py fp32=$out/pmc_fp32 bf16=$out/pmc_bf16 > $out/traffic.json
+python3 profiles/make_traffic.py fp32=$out/pmc_fp32 bf16=$out/pmc_bf16 bf16x3=$out/pmc_bf16x3 > $out/traffic.json
 find $out -name "*kernel_stats.csv" | head

@@ -4,8 +4,8 @@
 //  * stat_pool_kernel     -- stand-alone, HBM-bound: one pass over x with the first frame of
 //                            the utterance as a shift (sums of (x-K), (x-K)^2 are well
 //                            conditioned since K is a sample of the same distribution).
-//  * pool_finalize_kernel -- merges the per-sub-tile (mean, M2) partials that the layer-5
-//                            epilogue (tdnn_layer.hip) writes, with Chan's pairwise update.
+//  * pool_finalize_kernel -- adds up the per-sub-tile raw-sum partials that the layer-5
+//                            epilogues (tdnn_layer.hip, tdnn_pp.hip) write, in fp64.
 //
 // n == 1 gives NaN std exactly like torch.std (0/0); the caller rejects n < 1.
 #include "xvec_internal.h"
@@ -107,65 +107,46 @@ hipError_t launch_stat_pool(const PoolArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-// One thread per (utterance, channel): walk the sub-tiles the utterance's pooled rows touch,
-// recompute each one's row count from the geometry (the producer does not store it) and merge.
+// One thread per (utterance, channel): add up the raw-sum partials (S1, S2) = sums of r and r^2,
+// r = relu(z + bias), that the layer-5 epilogues (tdnn_layer.hip, tdnn_pp.hip) wrote per (32-row sub-tile,
+// utterance), then apply the folded BatchNorm y = scale*r + shift:
+//   mean = shift + scale*S1/n,   std = |scale| * sqrt((S2 - S1^2/n) / (n-1)),
+// totals and the difference in fp64.  Four sub-tiles per trip, their eight loads issued before the first add:
+// the kernel is a chain of ~10 dependent round trips per thread otherwise.
 __global__ __launch_bounds__(256) void pool_finalize_kernel(const PoolFinalizeArgs a) {
     const int u = blockIdx.y;
     const int ch = blockIdx.x * 256 + threadIdx.x;
     if (ch >= a.C) return;
     const int64_t off = row_off(a.map, u), end = row_off(a.map, u + 1);   // pooled rows are [off, end)
-    if (a.scale != nullptr) {
-        // raw-sum partials of tdnn_pp.hip: (S1, S2) = sums of r and r^2, r = relu(z + bias), per (sub-tile,
-        // utterance); y = scale*r + shift.  Totals and the difference S2 - S1^2/n in fp64.
-        double s1 = 0.0, s2 = 0.0;
-        for (int64_t sub = off / a.sub_rows; sub * a.sub_rows < end; ++sub) {
-            const float* p = a.part + (sub + u) * (int64_t)(2 * a.n_pad);
-            s1 += (double)p[ch];
-            s2 += (double)p[a.n_pad + ch];
-        }
-        const double n = (double)(end - off);
-        const double sc = (double)a.scale[ch], sh = (double)a.shift[ch];
-        const double mean_r = s1 / n;
-        double var_r = (s2 - s1 * mean_r) / (n - 1.0);
-        var_r = var_r > 0.0 ? var_r : 0.0;
-        float* o = a.out + (int64_t)u * 2 * a.C;
-        o[ch] = (float)(sh + sc * mean_r);
-        o[a.C + ch] = (n > 1.0) ? (float)((sc < 0.0 ? -sc : sc) * sqrt(var_r)) : __builtin_nanf("");
-        return;
-    }
-    float n = 0.f, mean = 0.f, m2 = 0.f;
-    // four sub-tiles per trip, their eight loads issued before the first merge: the kernel is a chain
-    // of ~10 dependent round trips per thread otherwise (12 us for 31 MB of partials)
-    for (int64_t sub0 = off / a.sub_rows; sub0 * a.sub_rows < end; sub0 += 4) {
-        float nb[4], mb[4], m2b[4];
+    double s1 = 0.0, s2 = 0.0;
+    const int64_t sub_end = (end + a.sub_rows - 1) / a.sub_rows;          // sub-tiles [off / sub_rows, sub_end)
+    for (int64_t sub0 = off / a.sub_rows; sub0 < sub_end; sub0 += 4) {
+        float p1[4], p2[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int64_t sub = sub0 + j;
-            const int64_t lo = sub * a.sub_rows > off ? sub * a.sub_rows : off;
-            const int64_t hi = (sub + 1) * a.sub_rows < end ? (sub + 1) * a.sub_rows : end;
-            nb[j] = hi > lo ? (float)(hi - lo) : 0.f;
-            mb[j] = 0.f;
-            m2b[j] = 0.f;
-            if (hi > lo) {
-                const float* p = a.part + (sub + u) * (int64_t)(2 * a.n_pad);
-                mb[j] = p[ch];
-                m2b[j] = p[a.n_pad + ch];
+            p1[j] = 0.f;
+            p2[j] = 0.f;
+            if (sub0 + j < sub_end) {
+                const float* p = a.part + (sub0 + j + u) * (int64_t)(2 * a.n_pad);
+                p1[j] = p[ch];
+                p2[j] = p[a.n_pad + ch];
             }
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            if (nb[j] > 0.f) {
-                const float nn = n + nb[j];
-                const float delta = mb[j] - mean;
-                mean += delta * (nb[j] / nn);
-                m2 += m2b[j] + delta * delta * (n * nb[j] / nn);
-                n = nn;
-            }
+            s1 += (double)p1[j];
+            s2 += (double)p2[j];
         }
     }
+    const double n = (double)(end - off);
+    const double sc = (double)a.scale[ch], sh = (double)a.shift[ch];
+    const double mean_r = s1 / n;
+    double var_r = (s2 - s1 * mean_r) / (n - 1.0);
+    var_r = var_r > 0.0 ? var_r : 0.0;
     float* o = a.out + (int64_t)u * 2 * a.C;
-    o[ch] = mean;
-    o[a.C + ch] = (n > 1.f) ? sqrtf(fmaxf(m2, 0.f) / (n - 1.f)) : __builtin_nanf("");
+    o[ch] = (float)(sh + sc * mean_r);
+    // n == 1 gives NaN like torch.std (0/0)
+    o[a.C + ch] = (n > 1.0) ? (float)((sc < 0.0 ? -sc : sc) * sqrt(var_r)) : __builtin_nanf("");
 }
 
 hipError_t launch_pool_finalize(const PoolFinalizeArgs& a, hipStream_t s) {

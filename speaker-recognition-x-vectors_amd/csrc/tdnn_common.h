@@ -126,15 +126,18 @@ __device__ __forceinline__ int64_t pool_first_row(const RowMap& m, int u) {
     return (int64_t)u * (m.fixed_T - m.cum);
 }
 
-// Fused statistics-pooling partial (main.py:59-63) of one 32-row group held in one accumulator:
-// for every utterance overlapping compact rows [row_g, row_g+32), the mean and M2 (sum of squared
-// deviations about that mean) of this lane's column over the utterance's frames in the group.
-// The epilogue's vector instructions only issue in the gaps the partner wave's MFMA stream leaves
-// on the SIMD, so their COUNT is what matters: paired (v_pk_*) arithmetic where the whole group
-// belongs to one utterance, 0/1 row weights from one bit mask where it does not.
+// Fused statistics-pooling partial (main.py:59-63) of one 32-row group held in one accumulator: for every
+// utterance overlapping compact rows [row_g, row_g+32), the RAW sums S1 = sum r, S2 = sum r^2 of this lane's
+// column over the utterance's frames in the group, r = relu(z + bias) (already applied to v).  pool_finalize
+// adds the partials of an utterance in fp64 and applies the folded BatchNorm there (mean = shift + scale*S1/n,
+// std = |scale|*sqrt((S2 - S1^2/n)/(n-1))).  Conditioning: the sums are taken in units of r, which does not
+// contain the BatchNorm shift (round 1 summed d = y - shift = scale*r per group and merged (mean, M2) pairs in
+// fp32 with Chan's update: the same fp32 sums per group, a longer fp32 chain across groups, and two more vector
+// instructions per value in an epilogue whose instruction COUNT is what matters -- it only issues in the gaps the
+// partner wave's MFMA stream leaves on the SIMD).
 template <bool RAGGED>
 __device__ __forceinline__ void pool_group_impl(const TdnnArgs& a, const f32x16& v, int64_t row_g, int h, int col,
-                                                float c, PoolCur& pc) {
+                                                PoolCur& pc) {
     const int64_t grp = row_g >> 5;
     const RowMap& m = a.out_map;
     const __amdgpu_buffer_rsrc_t prs = make_rsrc(a.pool_part);
@@ -142,23 +145,16 @@ __device__ __forceinline__ void pool_group_impl(const TdnnArgs& a, const f32x16&
         pc.u = __builtin_amdgcn_readfirstlane(pc.u + 1);
         pc.end = pool_first_row<RAGGED>(m, pc.u + 1);
     }
-    if (pc.end >= row_g + 32) {               // whole group inside utterance pc.u: no masks
-        // one pass, shifted by c like the masked path below (c = the column's BatchNorm shift: every value is
-        // relu(.)*scale + c, so s2 - s1^2/n does not cancel), two values per instruction; a mean-then-
-        // deviations second pass kept four more registers alive in an epilogue that has none to spare
+    if (pc.end >= row_g + 32) {               // whole group inside utterance pc.u: no masks, two values per instruction
         f32x2 p1 = {0.f, 0.f}, p2 = {0.f, 0.f};
-        const f32x2 cv = {c, c};
 #pragma unroll
         for (int e = 0; e < 16; e += 2) {
-            const f32x2 d = f32x2{v[e], v[e + 1]} - cv;
-            p1 += d;
-            p2 = __builtin_elementwise_fma(d, d, p2);
+            const f32x2 r = {v[e], v[e + 1]};
+            p1 += r;
+            p2 = __builtin_elementwise_fma(r, r, p2);
         }
         const float s1 = add_halves(p1.x + p1.y), s2 = add_halves(p2.x + p2.y);
-        const float dm = s1 * (1.f / 32.f);
-        const float mean = c + dm;
-        const float m2 = fmaxf(s2 - s1 * dm, 0.f);
-        store_partial(prs, a.ldy, grp + pc.u, h, col, mean, m2);
+        store_partial(prs, a.ldy, grp + pc.u, h, col, s1, s2);
         return;
     }
     for (int u = pc.u; u < m.n_utts; u = __builtin_amdgcn_readfirstlane(u + 1)) {
@@ -174,31 +170,25 @@ __device__ __forceinline__ void pool_group_impl(const TdnnArgs& a, const f32x16&
         const unsigned below_hi = hi_l >= 32 ? 0xffffffffu : ((1u << hi_l) - 1u);
         const unsigned rowmask = below_hi & ~((1u << lo_l) - 1u);
         const unsigned lm = rowmask >> (4 * h);
-        // one pass, shifted by c (the column's BatchNorm shift: every value is relu(.)*scale + c, so
-        // the mean lies within about one standard deviation of c and s2 - s1^2/n does not cancel)
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             // a SELECT, not a 0/1 weight: rows outside the utterance may be rows no layer wrote
             // (the tail of the last 32-row group), and 0 * Inf would poison the sums
-            const float d = ((lm >> ((e & 3) + 8 * (e >> 2))) & 1u) ? v[e] - c : 0.f;
-            s1 += d;
-            s2 = fmaf(d, d, s2);
+            const float r = ((lm >> ((e & 3) + 8 * (e >> 2))) & 1u) ? v[e] : 0.f;
+            s1 += r;
+            s2 = fmaf(r, r, s2);
         }
         s1 = add_halves(s1);
         s2 = add_halves(s2);
-        const float dm = s1 * (1.f / (float)(hi_l - lo_l));
-        const float mean = c + dm;
-        const float m2 = fmaxf(s2 - s1 * dm, 0.f);
-        store_partial(prs, a.ldy, grp + u, h, col, mean, m2);
+        store_partial(prs, a.ldy, grp + u, h, col, s1, s2);
     }
 }
 
 // (two code paths: see set_tile_rows in tdnn_layer.hip)
-__device__ __forceinline__ void pool_group(const TdnnArgs& a, const f32x16& v, int64_t row_g, int h, int col, float c,
-                                           PoolCur& pc) {
-    if (a.out_map.offsets == nullptr) pool_group_impl<false>(a, v, row_g, h, col, c, pc);
-    else pool_group_impl<true>(a, v, row_g, h, col, c, pc);
+__device__ __forceinline__ void pool_group(const TdnnArgs& a, const f32x16& v, int64_t row_g, int h, int col, PoolCur& pc) {
+    if (a.out_map.offsets == nullptr) pool_group_impl<false>(a, v, row_g, h, col, pc);
+    else pool_group_impl<true>(a, v, row_g, h, col, pc);
 }
 
 // cursor for a block whose first group starts at compact row `row`

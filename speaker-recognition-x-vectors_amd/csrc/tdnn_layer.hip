@@ -503,8 +503,9 @@ __device__ __forceinline__ void process_tile(const TdnnArgs& a, float* smem, Ctx
     }
 #define XV_EPI(i_)                                                                                        \
     if constexpr (G > i_) {                                                                               \
+        /* pooling variant: r = relu(z + bias) only; scale / shift are applied by pool_finalize */         \
         _Pragma("unroll") for (int e = 0; e < 16; ++e)                                                    \
-            acc##i_[e] = fmaf(fmaxf(acc##i_[e] + bi, 0.f), sc, sh);                                       \
+            acc##i_[e] = POOL ? fmaxf(acc##i_[e] + bi, 0.f) : fmaf(fmaxf(acc##i_[e] + bi, 0.f), sc, sh);  \
         asm volatile("" : "+v"(acc##i_));                                                                 \
         if (STORE) {                                                                                      \
             _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                              \
@@ -524,7 +525,7 @@ __device__ __forceinline__ void process_tile(const TdnnArgs& a, float* smem, Ctx
                 }                                                                                         \
             }                                                                                             \
         }                                                                                                 \
-        if (POOL) pool_group(a, acc##i_, m0 + i_ * 32, h, col, sh, cx.pool);                                           \
+        if (POOL) pool_group(a, acc##i_, m0 + i_ * 32, h, col, cx.pool);                                   \
     }
     if constexpr (SWAP) {
         float4 sc4[4], sh4[4];

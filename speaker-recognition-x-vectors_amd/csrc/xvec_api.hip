@@ -177,8 +177,7 @@ struct StageTimer {
 // x3: bf16x3 arithmetic -- X (and Y, when it is bf16) are two bf16 planes `x_plane` / `y_plane` bytes apart
 int run_tdnn(xvec_handle* h, int layer, TdnnVariant v, const void* X, int ldx, int64_t x_rows, void* Y,
              int64_t rows_out, const RowMap& out_map, float* part, hipStream_t s, bool x3 = false,
-             int64_t x_plane = 0, int64_t y_plane = 0, bool* raw_pool = nullptr) {
-    if (raw_pool) *raw_pool = false;
+             int64_t x_plane = 0, int64_t y_plane = 0) {
     const bool in16 = v == TdnnVariant::kBf16 || v == TdnnVariant::kBf16Pool || v == TdnnVariant::kBf16ToF32 ||
                       v == TdnnVariant::kBf16First || v == TdnnVariant::kBf16FirstToF32 || v == TdnnVariant::kBf16FirstSrc32;
     const TdnnGeom& g = in16 ? h->geo16[layer] : h->geo[layer];
@@ -250,7 +249,6 @@ int run_tdnn(xvec_handle* h, int layer, TdnnVariant v, const void* X, int ldx, i
             a.groups_total = units;
             a.pair_period = 0;
             HIP_TRY(launch_tdnn_pp(a, v == TdnnVariant::kBf16Pool, s));
-            if (raw_pool) *raw_pool = v == TdnnVariant::kBf16Pool;     // its pooling partials are raw sums
             return XVEC_OK;
         }
     }
@@ -319,14 +317,13 @@ int forward_rows(xvec_handle* h, const float* x_rows, int ldx, const int64_t* of
     }
     if ((size_t)p.part_slots * 2 * h->geo[4].n_pad * 4 > 0x7fffffffull)
         return fail(XVEC_ERR_ARG, "batch too large: pooling partials exceed 2 GiB; split it");
-    bool raw_pool = false;
     for (int l = 0; l < XVEC_NUM_TDNN; ++l) {
         map.cum += h->geo[l].ctx_span;
         const int64_t rows_out = p.total - (int64_t)B * map.cum;
         const TdnnVariant v = l == 0 ? v1 : l == 4 ? v5 : vm;
         void* out_buf = l == 4 ? nullptr : bufs[l & 1];
         if ((rc = run_tdnn(h, l, v, in, ld_in, l == 0 ? p.total : 0, out_buf, rows_out, map, l == 4 ? part : nullptr, s,
-                           x3, in_plane, l == 4 ? 0 : act_plane, l == 4 ? &raw_pool : nullptr)))
+                           x3, in_plane, l == 4 ? 0 : act_plane)))
             return rc;
         in = out_buf;
         ld_in = nh;
@@ -341,8 +338,8 @@ int forward_rows(xvec_handle* h, const float* x_rows, int ldx, const int64_t* of
         f.C = XVEC_POOL_CHANNELS;
         f.n_pad = h->geo[4].n_pad;
         f.sub_rows = 32;
-        f.scale = raw_pool ? h->vec[4] + f.n_pad : nullptr;
-        f.shift = raw_pool ? h->vec[4] + 2 * f.n_pad : nullptr;
+        f.scale = h->vec[4] + f.n_pad;              // the pooling epilogues leave raw sums of relu(z + bias)
+        f.shift = h->vec[4] + 2 * f.n_pad;
         HIP_TRY(launch_pool_finalize(f, s));
     }
     const int xv = h->cfg.x_vector_size, K6 = 2 * XVEC_POOL_CHANNELS;

@@ -99,7 +99,7 @@ struct TdnnArgs {
     RowMap out_map;           // row layout of THIS layer's output
     int span;                 // frames this layer consumes (c[-1]-c[0]): input row = p + u(p)*span
     // fused statistics-pooling epilogue (layer 5)
-    float* pool_part;         // [slots][2][n_pad] (mean, M2) per (32-row group, utterance)
+    float* pool_part;         // [slots][2][n_pad] raw sums (sum r, sum r^2), r = relu(z + bias), per (32-row group, utterance)
     // bf16x3 (fp32 values carried as two bf16 planes hi + lo, three bf16 products per k-step:
     // x_hi*W_hi + x_hi*W_lo + x_lo*W_hi).  terms == 2: X has a lo plane x_plane_bytes after the hi
     // plane and Wf holds, per chunk, the W_hi fragments followed by the W_lo fragments.
@@ -142,12 +142,12 @@ struct PoolArgs {
 hipError_t launch_stat_pool(const PoolArgs& a, hipStream_t s);
 
 struct PoolFinalizeArgs {
-    const float* part;       // [slots][2][n_pad]
+    const float* part;       // [slots][2][n_pad]: raw sums (S1, S2) of r = relu(z + bias) per (sub-tile, utterance)
     float* out;              // [B][2C]
     RowMap map;              // row layout of the pooled activation (layer 5 output)
     int C, n_pad, sub_rows;
-    const float* scale;      // nullptr: partials are (mean, M2) of the finished activation (tdnn_layer.hip);
-    const float* shift;      // else: raw sums (S1, S2) of relu(z + bias) (tdnn_pp.hip), y = scale*r + shift
+    const float* scale;      // folded BatchNorm of layer 5, applied here: y = scale*r + shift
+    const float* shift;
 };
 hipError_t launch_pool_finalize(const PoolFinalizeArgs& a, hipStream_t s);
 

@@ -95,7 +95,7 @@ hipError_t launch_pack_tdnn_bf16(const float* W, const TdnnGeom& geo, void* Wf16
     return hipGetLastError();
 }
 
-// bf16 weights for tdnn_pp.hip, K-TILE major: [256-channel column block][K-tile of 64][256 channels][64 k]
+// bf16 weights for tdnn_pp.hip, K-TILE major: [256-channel column block][K-tile of 64][256 rows][64 k]
 // (K order as everywhere: 64-element chunks, taps innermost).  Both operands of that kernel reach LDS by
 // DMA in 128-byte row slabs; a K-tile of a column block is then one contiguous 32 KiB, so the 256 CUs
 // that fetch the same tile at the same time spread over all L2 channels (128-byte slabs of plain rows,
@@ -108,7 +108,10 @@ __global__ void pack_tdnn_weight_ktile_kernel(const float* __restrict__ W, TdnnG
         const int w = (int)(i & 63), r = (int)((i >> 6) & 255);
         const int64_t t = i >> 14;                       // (column block, K-tile)
         const int cb = (int)(t / nk), q = (int)(t % nk);
-        const int n = cb * 256 + r, kd = tap_major_k(g, q * 64 + w);
+        // row r of a column block holds channel 64*wc + 2*l + j (wc = r >> 6, j = (r >> 5) & 1, l = r & 31): lane l of
+        // a wave's two accumulators then owns the ADJACENT channels 2l, 2l+1 of its 64-channel block, and the
+        // epilogues write them as one dword / one pair (tdnn_pp.hip)
+        const int n = cb * 256 + (r & ~63) + 2 * (r & 31) + ((r >> 5) & 1), kd = tap_major_k(g, q * 64 + w);
         const int tap = kd / g.tap_stride_src, c = kd % g.tap_stride_src;
         float v = 0.f;
         if (n < g.cout && tap < g.src_taps && c < g.src_cin)

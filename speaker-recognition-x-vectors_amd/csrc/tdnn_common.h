@@ -99,6 +99,16 @@ __device__ __forceinline__ void store_partial(__amdgpu_buffer_rsrc_t prs, int ld
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(h ? v1 : v0), prs, (col + h * ld) * 4, soff, 0);
 }
 
+// The same for TWO adjacent columns (col, col+1) held by one lane: one 8-byte store per lane, 256 contiguous
+// bytes per lane half (half 0: the S1 plane, half 1: the S2 plane).  col is even.
+__device__ __forceinline__ void store_partial2(__amdgpu_buffer_rsrc_t prs, int ld, int64_t slot, int h, int col, float s1a,
+                                               float s2a, float s1b, float s2b) {
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const int soff = (int)(slot * 2 * ld) * 4;
+    const u32x2 v = {__float_as_uint(h ? s2a : s1a), __float_as_uint(h ? s2b : s1b)};
+    __builtin_amdgcn_raw_buffer_store_b64(v, prs, (col + h * ld) * 4, soff, 0);
+}
+
 // Pooling cursor of a block: the utterance that holds the first row of the next 32-row group, and
 // the compact row where it ends.  Rows only grow along a block's range, so it advances with a few
 // scalar steps per group instead of a 64-bit division / binary search each time.

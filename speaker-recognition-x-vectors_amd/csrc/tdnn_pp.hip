@@ -38,9 +38,7 @@ constexpr int kAccRowB = 32 * kRowB;              // 32 frames: 4 KiB = 4 DMA pi
 constexpr int kABytes = 2 * 4 * kAccRowB;         // [group][acc row][32 frames]: 32 KiB
 constexpr int kWBytes = 256 * kRowB;              // 256 channels: 32 KiB = 32 DMA pieces
 constexpr int kBufBytes = kABytes + kWBytes;      // 64 KiB
-constexpr int kConstOff = 2 * kBufBytes;
-constexpr int kConstBytes = 3 * 256 * 4;          // bias | scale | shift of the block's 256 channels
-constexpr int kLdsBytes = kConstOff + kConstBytes;
+constexpr int kLdsBytes = 2 * kBufBytes;
 constexpr int kThreads = 512;
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -283,15 +281,11 @@ struct Lane {
         const unsigned o_ = ln.a_rd + (b_) * kBufBytes + (i_) * kAccRowB; \
         PP_RD(af##f_##_0, o_ + ln.k0) PP_RD(af##f_##_1, o_ + ln.k1) PP_RD(af##f_##_2, o_ + ln.k2) PP_RD(af##f_##_3, o_ + ln.k3) \
     }
-// one MFMA: accumulator (row i_, column j_), A fragment set f_, k-step s_.  Store variant: the weights
-// are the MFMA A operand (channels -> accumulator registers); pooling variant: the activations are.
+// one MFMA: accumulator (row i_, column j_), A fragment set f_, k-step s_.  The activations are the MFMA A
+// operand: frames in the accumulator's registers, the channel on the lane.
 #define PP_MF(i_, j_, f_, s_)                                                                                      \
-    if constexpr (POOL)                                                                                            \
-        acc##i_##j_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af##f_##_##s_),           \
-                                                              __builtin_bit_cast(bf16x8, wf##j_##_##s_), acc##i_##j_, 0, 0, 0); \
-    else                                                                                                           \
-        acc##i_##j_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf##j_##_##s_),           \
-                                                              __builtin_bit_cast(bf16x8, af##f_##_##s_), acc##i_##j_, 0, 0, 0);
+    acc##i_##j_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af##f_##_##s_),               \
+                                                          __builtin_bit_cast(bf16x8, wf##j_##_##s_), acc##i_##j_, 0, 0, 0);
 
 // One MFMA step (k-step s_) of acc rows i0_, i1_ (fragment sets of the same number) x both columns
 #define PP_MF4(i0_, i1_, s_) PP_MF(i0_, 0, i0_, s_) PP_MF(i0_, 1, i0_, s_) PP_MF(i1_, 0, i1_, s_) PP_MF(i1_, 1, i1_, s_)
@@ -394,8 +388,8 @@ struct Lane {
 // by pool_finalize (mean = shift + scale*S1/n, std = |scale|*sqrt((S2 - S1^2/n)/(n-1)) with the totals and
 // the difference taken in fp64); r >= 0 keeps the cancellation in S2 - S1^2/n mild (relative error of the
 // variance ~1e-7*(1 + mean^2/var)), far inside this bf16 path's 1e-2 bar.
-// v0 / v1: the accumulators of this wave's two 32-channel columns for the group at compact row row_g
-// (bias already inside: the accumulators start at it).
+// v0 / v1: this wave's two accumulators for the group at compact row row_g -- the lane's channels col0 and
+// col0 + 1 (bias already inside: the accumulators start at it).
 // Returns true when the group lay inside one utterance.
 // RAGGED is a template parameter and the utterance index is kept provably wave-uniform on purpose: with
 // a run-time "offsets ? load : multiply" hipcc emitted VECTOR loads of the offsets followed by
@@ -432,8 +426,7 @@ __device__ __forceinline__ bool pool_raw_pair(const TdnnArgs& a, const f32x16& v
         }
         const float s1a = add_halves(p1a.x + p1a.y), s2a = add_halves(p2a.x + p2a.y);
         const float s1b = add_halves(p1b.x + p1b.y), s2b = add_halves(p2b.x + p2b.y);
-        store_partial(prs, ld, grp + pc.u, h, col0, s1a, s2a);
-        store_partial(prs, ld, grp + pc.u, h, col0 + 32, s1b, s2b);
+        store_partial2(prs, ld, grp + pc.u, h, col0, s1a, s2a, s1b, s2b);
         return true;
     }
     for (int u = pc.u; u < m.n_utts; u = __builtin_amdgcn_readfirstlane(u + 1)) {   // the group straddles utterances
@@ -460,41 +453,31 @@ __device__ __forceinline__ bool pool_raw_pair(const TdnnArgs& a, const f32x16& v
         s2a = add_halves(s2a);
         s1b = add_halves(s1b);
         s2b = add_halves(s2b);
-        store_partial(prs, ld, grp + u, h, col0, s1a, s2a);
-        store_partial(prs, ld, grp + u, h, col0 + 32, s1b, s2b);
+        store_partial2(prs, ld, grp + u, h, col0, s1a, s2a, s1b, s2b);
     }
     return false;
 }
+
+// epilogue constants of a lane's two channels (n0 + 64*wc + 2r, +1), in registers for the whole launch
+struct Consts {
+    float bi0, bi1, sc0, sc1, sh0, sh1;
+};
 
 // One tile: K loop, request of the next tile's first K-tiles, epilogue.
 template <int MR, bool POOL>
 __device__ __forceinline__ void process_tile(const TdnnArgs& a, char* smem, Stream& st, const Lane& ln,
                                              const Tile& t, const Tile& nxt, bool has_next, bool first, int n0, int nk,
-                                             PoolCur& pc, float bi0, float bi1) {
+                                             PoolCur& pc, const Consts& cs) {
     // source rows of the NEXT tile (its first K-tiles are requested during this tile's last two): worked out
     // here, before the accumulators exist, and parked in four registers
     Rows rows_next = st.cur;
     if (has_next) set_rows(a, nxt, ln.grp, st, rows_next);
-    // the accumulators start at the bias: of their lane's channel (pooling variant: channel on the lane), or of
-    // each register's channel (store variant: 16 channels per lane and column, from the LDS copy)
+    // the accumulators start at the bias of their lane's channel
     f32x16 acc00, acc01, acc10, acc11, acc20, acc21, acc30, acc31;
-    if constexpr (POOL) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            acc00[e] = bi0; acc01[e] = bi1; acc10[e] = bi0; acc11[e] = bi1;
-            acc20[e] = bi0; acc21[e] = bi1; acc30[e] = bi0; acc31[e] = bi1;
-        }
-    } else {
-        const char* cb = smem + kConstOff + (ln.wc * 64 + 4 * ln.h) * 4;
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-            const float4 b0 = *reinterpret_cast<const float4*>(cb + gq * 32);
-            const float4 b1 = *reinterpret_cast<const float4*>(cb + 128 + gq * 32);
-            acc00[4 * gq] = b0.x; acc00[4 * gq + 1] = b0.y; acc00[4 * gq + 2] = b0.z; acc00[4 * gq + 3] = b0.w;
-            acc01[4 * gq] = b1.x; acc01[4 * gq + 1] = b1.y; acc01[4 * gq + 2] = b1.z; acc01[4 * gq + 3] = b1.w;
-        }
-        acc10 = acc00; acc20 = acc00; acc30 = acc00;
-        acc11 = acc01; acc21 = acc01; acc31 = acc01;
+    for (int e = 0; e < 16; ++e) {
+        acc00[e] = cs.bi0; acc01[e] = cs.bi1; acc10[e] = cs.bi0; acc11[e] = cs.bi1;
+        acc20[e] = cs.bi0; acc21[e] = cs.bi1; acc30[e] = cs.bi0; acc31[e] = cs.bi1;
     }
     float4 wf0_0, wf0_1, wf0_2, wf0_3, wf1_0, wf1_1, wf1_2, wf1_3;
     float4 af0_0, af0_1, af0_2, af0_3, af1_0, af1_1, af1_2, af1_3;     // acc rows 0,1 (read during the previous mfma 1)
@@ -563,34 +546,26 @@ __device__ __forceinline__ void process_tile(const TdnnArgs& a, char* smem, Stre
     if constexpr (PP_KNOCK_EPI) {
         asm volatile("" ::"v"(acc00), "v"(acc01), "v"(acc10), "v"(acc11), "v"(acc20), "v"(acc21), "v"(acc30), "v"(acc31));
     } else if constexpr (!POOL) {
+        // ReLU + folded BatchNorm (tdnn_layer.py:30-39); the lane's two channels are adjacent (pack.hip), so one
+        // v_cvt_pk_bf16_f32 makes the dword of column 2r and a store instruction writes two whole 128-byte row
+        // segments (lane halves = rows 4 apart).  Element e of an accumulator = frame (e&3) + 8*(e>>2) + 4*h.
+        typedef float f32x2v __attribute__((ext_vector_type(2)));
         const __amdgpu_buffer_rsrc_t yrsrc = make_rsrc(static_cast<char*>(a.Y) + (t.m0 * (int64_t)a.ldy + n0) * 2);
-        const int y_voff = (ln.r * a.ldy + ln.wc * 64 + 8 * ln.h) * 2;
-        const char* cst = smem + kConstOff + (ln.wc * 64 + 4 * ln.h) * 4;
-#define PP_STORE(i_, j_)                                                                               \
+        const int y_voff = (4 * ln.h * a.ldy + ln.wc * 64 + 2 * ln.r) * 2;
+#define PP_STORE(i_)                                                                                   \
         if (MR > i_ && row0 + 32 * i_ < t.valid_end) {                                                    \
-            store_acc(acc##i_##j_, sc, sh, yrsrc, y_voff, (ln.grp * 32 * MR + 32 * i_) * a.ldy * 2 + 64 * j_); \
+            _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                              \
+                const float v0 = fmaf(fmaxf(acc##i_##0[e], 0.f), cs.sc0, cs.sh0);                         \
+                const float v1 = fmaf(fmaxf(acc##i_##1[e], 0.f), cs.sc1, cs.sh1);                         \
+                const unsigned pk = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{v0, v1}, bf16x2)); \
+                __builtin_amdgcn_raw_buffer_store_b32(pk, yrsrc, y_voff,                                  \
+                                                      (ln.grp * 32 * MR + 32 * i_ + (e & 3) + 8 * (e >> 2)) * a.ldy * 2, 0); \
+            }                                                                                             \
         }
-        {
-            float4 sc[4], sh[4];
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                sc[gq] = *reinterpret_cast<const float4*>(cst + 1024 + gq * 32);
-                sh[gq] = *reinterpret_cast<const float4*>(cst + 2048 + gq * 32);
-            }
-            PP_STORE(0, 0) PP_STORE(1, 0) PP_STORE(2, 0) PP_STORE(3, 0)
-        }
-        {
-            float4 sc[4], sh[4];
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                sc[gq] = *reinterpret_cast<const float4*>(cst + 128 + 1024 + gq * 32);
-                sh[gq] = *reinterpret_cast<const float4*>(cst + 128 + 2048 + gq * 32);
-            }
-            PP_STORE(0, 1) PP_STORE(1, 1) PP_STORE(2, 1) PP_STORE(3, 1)
-        }
+        PP_STORE(0) PP_STORE(1) PP_STORE(2) PP_STORE(3)
 #undef PP_STORE
     } else {
-        const int col0 = n0 + ln.wc * 64 + ln.r;
+        const int col0 = n0 + ln.wc * 64 + 2 * ln.r;
 #define PP_POOL(RG_, i_)                                                                               \
         if (MR > i_ && row0 + 32 * i_ < t.valid_end) {                                                    \
             pool_raw_pair<RG_>(a, acc##i_##0, acc##i_##1, row0 + 32 * i_, ln.h, col0, pc);                \
@@ -646,17 +621,16 @@ __global__ __launch_bounds__(kThreads, 2) void tdnn_pp_kernel(const TdnnArgs a) 
     ln.a_rd = ln.grp * 4 * kAccRowB + ln.rd;
     ln.w_rd = kABytes + ln.wc * 2 * kAccRowB + ln.rd;
 
-    // per-channel constants of the block's column -> LDS (store variant reads them per register)
-    if (tid < 192) {
-        const int arr = tid >> 6, c4 = (tid & 63) * 4;
-        const float* src = arr == 0 ? a.bias : arr == 1 ? a.scale : a.shift;
-        *reinterpret_cast<float4*>(smem + kConstOff + arr * 1024 + c4 * 4) = *reinterpret_cast<const float4*>(src + n0 + c4);
-    }
-    float bi0 = 0.f, bi1 = 0.f;
-    if (POOL) {
-        const int c = n0 + ln.wc * 64 + ln.r;
-        bi0 = a.bias[c];
-        bi1 = a.bias[c + 32];
+    Consts cs;
+    {
+        const int c = n0 + ln.wc * 64 + 2 * ln.r;
+        const float2 b2 = *reinterpret_cast<const float2*>(a.bias + c);
+        cs.bi0 = b2.x; cs.bi1 = b2.y;
+        cs.sc0 = cs.sc1 = cs.sh0 = cs.sh1 = 0.f;
+        if (!POOL) {
+            const float2 s2 = *reinterpret_cast<const float2*>(a.scale + c), h2 = *reinterpret_cast<const float2*>(a.shift + c);
+            cs.sc0 = s2.x; cs.sc1 = s2.y; cs.sh0 = h2.x; cs.sh1 = h2.y;
+        }
     }
 
     // DMA map of this wave: piece row = lane >> 3 (8 rows per piece), LDS position lane & 7 holds the
@@ -701,7 +675,6 @@ __global__ __launch_bounds__(kThreads, 2) void tdnn_pp_kernel(const TdnnArgs a) 
         Tile cur = tile_at(0, u_begin * 64);
         if (POOL) pc = pool_cursor(a, cur.m0 + ln.grp * 32 * cur.mr);
         set_rows(a, cur, ln.grp, st, st.cur);
-        __syncthreads();                                   // constants visible; nobody reads LDS buffers yet
         issue_head1(a, st, cur.mr);
         issue_head2(a, st, cur.mr);
         for (int idx = 0; idx < nt; ++idx) {
@@ -709,9 +682,9 @@ __global__ __launch_bounds__(kThreads, 2) void tdnn_pp_kernel(const TdnnArgs a) 
             Tile nxt = cur;
             if (has_next) nxt = tile_at(idx + 1, cur.m0 + 64 * cur.mr);
             if (cur.mr == 4)
-                process_tile<4, POOL>(a, smem, st, ln, cur, nxt, has_next, idx == 0, n0, nk, pc, bi0, bi1);
+                process_tile<4, POOL>(a, smem, st, ln, cur, nxt, has_next, idx == 0, n0, nk, pc, cs);
             else
-                process_tile<3, POOL>(a, smem, st, ln, cur, nxt, has_next, idx == 0, n0, nk, pc, bi0, bi1);
+                process_tile<3, POOL>(a, smem, st, ln, cur, nxt, has_next, idx == 0, n0, nk, pc, cs);
             cur = nxt;
         }
     }

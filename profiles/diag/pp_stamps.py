@@ -43,3 +43,12 @@ for layer in layers:
             v = a[:, g, k].mean()
             unit = v / a[:, g, 14].mean() if k in PER_TILE else v / (a[:, g, 14].mean() * nk)
             print(f"    {names[k]:14s} {v:10.0f} cycles/block  {100 * v / tot:5.1f} %   {unit:8.1f} per {'tile' if k in PER_TILE else 'K-tile'}")
+    try:        # core clock during the launch: block 0's s_memtime (core cycles) over s_memrealtime (100 MHz)
+        ck = (C.c_ulonglong * 8)()
+        hip.lib.xvec_pp_clk_read.argtypes = [C.c_void_p]
+        if hip.lib.xvec_pp_clk_read(ck) == 0:
+            o = 4 if layer == 4 else 0
+            dt_core, dt_real = ck[o + 2] - ck[o + 0], ck[o + 3] - ck[o + 1]
+            print(f"  block 0: {dt_core} core cycles in {dt_real / 100:.1f} us -> {dt_core / (dt_real / 100) / 1e3:.2f} GHz")
+    except AttributeError:
+        pass

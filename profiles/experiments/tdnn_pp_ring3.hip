@@ -35,12 +35,10 @@ namespace pp {
 
 constexpr int kRowB = 128;                        // one K-tile slab of one row: 64 bf16
 constexpr int kAccRowB = 32 * kRowB;              // 32 frames: 4 KiB = 4 DMA pieces
-constexpr int kABytes = 2 * 3 * kAccRowB;         // activation buffer [group][acc row][32 frames]: 24 KiB, two of them
-constexpr int kWBytes = 256 * kRowB;              // 256 channels: 32 KiB = 32 DMA pieces
+constexpr int kABytes = 2 * 4 * kAccRowB;         // activation buffer [group][acc row][32 frames]: 32 KiB, two of them
+constexpr int kWBytes = 256 * kRowB;              // 256 channel rows: 32 KiB = 32 DMA pieces
 constexpr int kWOff = 2 * kABytes;                // weight ring: three K-tiles
-constexpr int kConstOff = kWOff + 3 * kWBytes;
-constexpr int kConstBytes = 3 * 256 * 4;          // bias | scale | shift of the block's 256 channels
-constexpr int kLdsBytes = kConstOff + kConstBytes;
+constexpr int kLdsBytes = kWOff + 3 * kWBytes;    // 160 KiB: all of a CU's LDS
 constexpr int kThreads = 512;
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -120,8 +118,8 @@ __device__ unsigned long long g_pp_diag[2 * 512 * 32];   // [pooling variant][bl
 #define PP_WAIT_VM_RT(n_)                                        \
     {                                                            \
         const int nn_ = (n_);                                    \
-        if (nn_ == 11) { PP_WAIT_VM(11); }                       \
-        else if (nn_ == 10) { PP_WAIT_VM(10); }                  \
+        if (nn_ == 10) { PP_WAIT_VM(10); }                       \
+        else if (nn_ == 9) { PP_WAIT_VM(9); }                    \
         else if (nn_ == 8) { PP_WAIT_VM(8); }                    \
         else if (nn_ == 7) { PP_WAIT_VM(7); }                    \
         else if (nn_ == 6) { PP_WAIT_VM(6); }                    \
@@ -224,12 +222,13 @@ __device__ __forceinline__ void kstep(const TdnnArgs& a, KPos& k) {
     }
 }
 
-// --- DMA piece groups of one wave (buffer b_ = parity of the K-tile) -------------------------
-// W: the wave's four pieces (channel rows 8*(wave + 8t) ..+7); A01 / A23: its piece of acc rows 0,1 / 2,(3)
+// --- DMA piece groups of one wave ------------------------------------------------------------
+// W: the wave's four pieces (channel rows 8*(wave + 8t) ..+7) of W K-tile q_ into ring slot slot_;
+// A01 / A23: its piece of acc rows 0,1 / 2,(3) into activation buffer b_
 #define PP_ISSUE_W(slot_, q_)                                                       \
     {                                                                               \
         const int so_ = (q_) * kWBytes;              /* K-tile major weights: 32 KiB per K-tile */ \
-        const unsigned d_ = st.lds_w + (slot_) * kWBytes;   /* ring slot 0..2 (scalar) */ \
+        const unsigned d_ = st.lds_w + (slot_) * kWBytes;                           \
         dma16(st.wrsrc, d_, st.wv0, so_);                                           \
         dma16(st.wrsrc, d_ + 8 * 1024, st.wv0, so_ + st.w64);                       \
         dma16(st.wrsrc, d_ + 16 * 1024, st.wv0, so_ + 2 * st.w64);                  \
@@ -240,24 +239,26 @@ __device__ __forceinline__ void kstep(const TdnnArgs& a, KPos& k) {
         dma16(st.cur.xrsrc, st.lds_a + (b_) * kABytes, st.cur.av0, so_);                    \
         dma16(st.cur.xrsrc, st.lds_a + (b_) * kABytes + kAccRowB, st.cur.av1, so_);         \
     }
-#define PP_ISSUE_A2(MR_, b_, so_)                                                   \
+#define PP_ISSUE_A23(MR_, b_, so_)                                                  \
     {                                                                               \
-        if ((MR_) > 2) dma16(st.cur.xrsrc, st.lds_a + (b_) * kABytes + 2 * kAccRowB, st.cur.av2, so_);     \
+        dma16(st.cur.xrsrc, st.lds_a + (b_) * kABytes + 2 * kAccRowB, st.cur.av2, so_);     \
+        if ((MR_) > 3) dma16(st.cur.xrsrc, st.lds_a + (b_) * kABytes + 3 * kAccRowB, st.cur.av3, so_); \
     }
 
-// A block's first requests, in the K loop's request order -- W(q+2), rows(q+1), W(q+3), rows(q+2), ... -- so that
-// the loop's counted waits hold from the first K-tile: W(0), W(1), rows(0), W(2), rows(1); the loop goes on with
-// W(3) (load 0 of K-tile 0), rows(2) (load 1), ...  W of K-tile x lives in ring slot x % 3.
+// A block's first requests, in the K loop's request order -- rows 0,1 (x), W(x+1), rows 2,3 (x), rows 0,1 (x+1),
+// W(x+2), ... -- so that the loop's counted waits hold from the first K-tile: W(0), then K-tiles 0 and 1 in that
+// order with W(1), W(2); the loop goes on with rows 0,1 of K-tile 2 (load 0 of K-tile 0), W(3), rows 2,3 of
+// K-tile 2 (load 1), ...  W of K-tile x lives in ring slot x mod 3 (counted over the block).
 __device__ __forceinline__ void issue_head(const TdnnArgs& a, const Stream& st, int mr) {
     KPos k1 = {0, 0};
     kstep(a, k1);
     PP_ISSUE_W(0, 0)
-    PP_ISSUE_W(1, 1)
     PP_ISSUE_A01(0, 0)
-    PP_ISSUE_A2(mr, 0, 0)
-    PP_ISSUE_W(2, 2)
+    PP_ISSUE_W(1, 1)
+    PP_ISSUE_A23(mr, 0, 0)
     PP_ISSUE_A01(1, k1.so)
-    PP_ISSUE_A2(mr, 1, k1.so)
+    PP_ISSUE_W(2, 2)
+    PP_ISSUE_A23(mr, 1, k1.so)
 }
 
 struct Lane {
@@ -272,93 +273,93 @@ struct Lane {
 #define PP_RD(dst_, off_) if constexpr (!PP_KNOCK_RD) dst_ = *reinterpret_cast<const float4*>(smem + (off_));
 #define PP_RDW(dst_, off_) if constexpr (!PP_KNOCK_RDW) PP_RD(dst_, off_)
 // one W fragment: register set S_ (a / b: the K-tile being multiplied and the next one alternate), column j_,
-// k-step s_, from buffer b_
+// k-step s_, from the ring slot at LDS offset base_ (this wave's channel rows, + the lane's row)
 #define PP_RW(S_, j_, s_, base_) PP_RDW(w##S_##j_##_##s_, (base_) + (j_) * kAccRowB + ln.k##s_)
-// one MFMA: accumulator (row i_, column j_), A fragment set f_, k-step s_, W register set S_.  Store variant: the
-// weights are the MFMA A operand (channels -> accumulator registers); pooling variant: the activations are.
-#define PP_MF(S_, i_, j_, f_, s_)                                                                                  \
-    if constexpr (POOL)                                                                                            \
-        acc##i_##j_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af##f_##_##s_),           \
-                                                              __builtin_bit_cast(bf16x8, w##S_##j_##_##s_), acc##i_##j_, 0, 0, 0); \
-    else                                                                                                           \
-        acc##i_##j_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w##S_##j_##_##s_),        \
-                                                              __builtin_bit_cast(bf16x8, af##f_##_##s_), acc##i_##j_, 0, 0, 0);
+// one activation fragment: acc row i_, k-step s_, from buffer b_, into fragment set f_
+#define PP_RA(f_, i_, s_, b_) if constexpr (!PP_KNOCK_RDA) PP_RD(af##f_##_##s_, ln.a_rd + (b_) * kABytes + (i_) * kAccRowB + ln.k##s_)
+// one MFMA: accumulator (row i_, column j_), A fragment set f_, k-step s_, W register set S_.  The activations are
+// the MFMA A operand: frames in the accumulator's registers, the channel on the lane.  SB(): to be followed by ONE
+// LDS read -- a ds_read_b128 holds the wave's issue for ~30 cycles (stamps, profiles/diag/pp_stamps.py), which is
+// free exactly when an MFMA of this wave is executing (32 cycles), so reads and MFMAs alternate one to one.
+#define PP_M1(S_, i_, j_, f_, s_)                                                                                  \
+    acc##i_##j_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af##f_##_##s_),               \
+                                                          __builtin_bit_cast(bf16x8, w##S_##j_##_##s_), acc##i_##j_, 0, 0, 0); \
+    SB();
 
-// One MFMA step (k-step s_) of acc rows 0, 1 (fragment sets of the same number) x both columns
-#define PP_MF4(S_, s_) PP_MF(S_, 0, 0, 0, s_) PP_MF(S_, 0, 1, 0, s_) PP_MF(S_, 1, 0, 1, s_) PP_MF(S_, 1, 1, 1, s_)
-// a single MFMA (acc row i_, column j_, k-step s_; fragment set = row), to be followed by ONE LDS read: a
-// ds_read_b128 holds the wave's issue for ~30 cycles (stamps, profiles/diag/pp_stamps.py), which is free
-// exactly when an MFMA of this wave is executing (32 cycles) -- so reads and MFMAs alternate one to one
-#define PP_M1(S_, i_, j_, s_) PP_MF(S_, i_, j_, i_, s_) SB();
-// one activation fragment read: acc row i_ (= fragment set i_), k-step s_, from buffer b_
-#define PP_RA(i_, s_, b_) if constexpr (!PP_KNOCK_RDA) PP_RD(af##i_##_##s_, ln.a_rd + (b_) * kABytes + (i_) * kAccRowB + ln.k##s_)
-
-// One K-tile held in LDS buffer b_ (odd_ = its parity); WC_ / WN_ = the register sets (a, b) of its weight
-// fragments and of the next K-tile's.  k2.so / wq = activation source offset and index of the K-tile requested
-// now, two K-tiles ahead; mr_req = height of the tile it belongs to.  The request stream does not stop at the
-// end of a tile: in a tile's last two K-tiles ("last") the requests are the NEXT tile's K-tiles 0 and 1 (the
-// stream state was switched to that tile just before), so a tile starts with its first K-tiles in LDS.  Only a
-// block's last tile requests nothing there.
-//   load 0:  request W of K-tile q+2 (4 pieces)
-//   mfma 0:  MR=3: acc rows 0,1, k-steps 0-2 (12 MFMAs), behind them the 4 fragment reads of acc row 2 and the
-//            8 W fragment reads of K-tile q+1;  MR=2: acc rows 0,1, k-steps 0,1 (8) with the 8 W reads
-//   load 1:  request acc rows 0,1,(2) of K-tile q+2 (2-3 pieces)
-//   mfma 1:  MR=3: acc rows 0,1 k-step 3, then acc row 2 (12) with the 8 fragment reads of acc rows 0,1 of
-//            K-tile q+1 behind the acc row 2 MFMAs;  MR=2: k-steps 2,3 (8) with those 8 reads, each one behind
-//            the last MFMA that uses the register it overwrites
-// NO fragment is read in a load segment (round 2's first version read the 8 W fragments there: ~300 cycles of
-// a 650-cycle load segment, against MFMA segments of 430-490 -- the other group's MFMAs waited at the barrier).
-// A load segment is now the 2-4 DMA instructions and the counted wait; the W fragments cost 32 more registers,
-// which is why tiles are 3 or 2 accumulator rows high, not 4.  W is read in mfma 0 ONLY: the other group runs
-// one segment behind, and W of K-tile q+2 overwrites W of K-tile q at this group's load 0 -- by then the other
-// group is in its mfma 1 of K-tile q-1 and must be done with W of K-tile q.
-// The two segments of a wave are equally long, so the SIMD partner's load segments have the same time to
-// hide in.  Every segment ends with lgkmcnt(0) before its barrier (a slot may be refilled in any later segment).
-// Counted vmcnt at the end of a load segment.  Request order per wave: W(q) [4] | rows 0,1 (q) [2], row 2 (q)
-// [a = MR - 2] | W(q+1) ...; a1, a2 = a of the tiles K-tiles q+1, q+2 belong to:
-//   load 0 must have W of K-tile q+1 (everything older with it, row 2 of K-tile q included):
-//          younger = rows(q+1) [2 + a1] + W(q+2) [4]
-//   load 1 must have rows 0,1 of K-tile q+1:  younger = a1 + W(q+2) [4] + rows(q+2) [2 + a2]
-// -- never a drain, except where nothing further was requested.  (The epilogue's stores sit in the same queue:
-// the first waits of the next tile then wait for a few entries more than they need to, long completed.)
+// One K-tile, activations in LDS buffer b_ (odd_ = its parity), weights in ring slot `ws`; WC_ / WN_ = the
+// register sets (a, b) of its weight fragments and of the next K-tile's in a 3-row tile (a 4-row tile keeps ONE
+// set, a, and refills it in place).  k2.so = activation source offset of the K-tile requested now (two ahead),
+// mr_req = height of the tile it belongs to; wq = index of the W K-tile requested now (three ahead; it simply
+// wraps round into the next tile -- the weights do not depend on the tile).  The activation request stream does
+// not stop at the end of a tile either: in a tile's last two K-tiles ("last") it asks for the NEXT tile's K-tiles
+// 0 and 1 (the stream state was switched to that tile just before).
+//   load 0:  request acc rows 0,1 of K-tile q+2 (2 pieces)
+//   mfma 0:  MR=4: acc rows 0,1 (16 MFMAs) with the 8 fragment reads of acc rows 2,3 behind them -- INTO THE
+//            REGISTERS OF rows 0,1, each read behind the last MFMA that uses its target;
+//            MR=3: acc rows 0,1, k-steps 0-2 (12), with the 4 reads of acc row 2 (own registers) and the 8 W
+//            fragment reads of K-tile q+1 into the other W set
+//   load 1:  request W of K-tile q+3 (4 pieces, into the slot of K-tile q) and acc rows 2,(3) of K-tile q+2
+//   mfma 1:  MR=4: acc rows 2,3 (16) with, behind them, the 8 fragment reads of acc rows 0,1 of K-tile q+1 and
+//            the 8 W fragment reads of K-tile q+1, all into registers whose last use was the MFMA just issued;
+//            MR=3: acc rows 0,1 k-step 3, then acc row 2 (12) with the 8 reads of acc rows 0,1 of K-tile q+1
+// NO fragment is read in a load segment (the first version of this kernel read the 8 W fragments in load 0: ~300
+// of a 650-cycle load segment against MFMA segments of 430-490 -- the other group's MFMAs waited at the barrier).
+// Why a ring of THREE weight slots.  The two groups run one segment apart and share W.  W of K-tile q+3 may be
+// requested only when the OTHER group has read the slot's tenant, W(q) -- it does so in its mfma 1 of K-tile q-1 at
+// the latest, which runs beside this group's load 0 of K-tile q: hence load 1.  And before this group reads
+// W(q+1) in its mfma 0 of K-tile q, the other group's pieces of it must have landed, i.e. that group must have
+// waited in a load segment that ended earlier: its load 1 of K-tile q-1.  Request in load 1, wait four segments
+// later in load 1: three K-tiles of W are in flight or in use at any time.
+// Counted vmcnt at the end of a load segment.  Request order per wave: rows01(x) [2], W(x+1) [4], rows23(x) [a],
+// rows01(x+1), ...; a = MR - 2 of the tile the K-tile belongs to (a1, a2: of K-tiles q+1, q+2):
+//   load 0 must have rows 2,3 of K-tile q:  younger = rows01(q+1) + W(q+2) + rows23(q+1) + rows01(q+2) = 8 + a1
+//   load 1 must have W of K-tile q+2 (rows 0,1 of K-tile q+1, needed next, are older):
+//          younger = rows23(q+1) + rows01(q+2) + W(q+3) + rows23(q+2) = 6 + a1 + a2
+// -- never a drain.  (The epilogue's stores sit in the same queue: the first waits of the next tile then wait for a
+// few entries more than they need to, long completed.)
 #define PP_KTILE(b_, odd_, WC_, WN_)                                                \
     {                                                                               \
         SB();                                                                       \
-        if (!PP_KNOCK_DMA) PP_ISSUE_W(ws, wq)          /* W of K-tile q+3 -> the slot of K-tile q */ \
+        if (req && !PP_KNOCK_DMA) PP_ISSUE_A01(b_, k2.so)                           \
         const unsigned wrd = ln.w_rd + (ws == 2 ? 0 : ws + 1) * kWBytes;   /* slot of K-tile q+1 */ \
         SB();                                                                       \
         PP_STAMP(0)                                                                 \
-        if (!(last && (odd_))) { if (MR == 3) { PP_WAIT_VM(11); } else { PP_WAIT_VM(10); } } \
-        else { PP_WAIT_VM_RT(req ? mr_req + 8 : 8) }                                \
+        if (!last) { if (MR == 4) { PP_WAIT_VM(10); } else { PP_WAIT_VM(9); } }     \
+        else if (!(odd_)) { PP_WAIT_VM_RT(req ? MR + 6 : MR + 4) }                  \
+        else { PP_WAIT_VM_RT(req ? mr_req + 6 : 4) }                                \
         PP_STAMP(1)                                                                 \
         PP_BARRIER()                                                                \
         PP_STAMP(2)                                                                 \
         __builtin_amdgcn_s_setprio(1);                                              \
-        if constexpr (MR == 3) {                                                    \
-            PP_M1(WC_, 0, 0, 0) PP_RA(2, 0, b_) SB(); PP_M1(WC_, 0, 1, 0) PP_RA(2, 1, b_) SB(); \
-            PP_M1(WC_, 1, 0, 0) PP_RA(2, 2, b_) SB(); PP_M1(WC_, 1, 1, 0) PP_RA(2, 3, b_) SB(); \
-            PP_M1(WC_, 0, 0, 1) PP_RW(WN_, 0, 0, wrd) SB(); PP_M1(WC_, 0, 1, 1) PP_RW(WN_, 0, 1, wrd) SB(); \
-            PP_M1(WC_, 1, 0, 1) PP_RW(WN_, 0, 2, wrd) SB(); PP_M1(WC_, 1, 1, 1) PP_RW(WN_, 0, 3, wrd) SB(); \
-            PP_M1(WC_, 0, 0, 2) PP_RW(WN_, 1, 0, wrd) SB(); PP_M1(WC_, 0, 1, 2) PP_RW(WN_, 1, 1, wrd) SB(); \
-            PP_M1(WC_, 1, 0, 2) PP_RW(WN_, 1, 2, wrd) SB(); PP_M1(WC_, 1, 1, 2) PP_RW(WN_, 1, 3, wrd) SB(); \
+        if constexpr (MR == 4) {                                                    \
+            PP_M1(a, 0, 0, 0, 0) PP_M1(a, 0, 1, 0, 0) PP_RA(0, 2, 0, b_) SB();     \
+            PP_M1(a, 1, 0, 1, 0) PP_M1(a, 1, 1, 1, 0) PP_RA(1, 3, 0, b_) SB();     \
+            PP_M1(a, 0, 0, 0, 1) PP_M1(a, 0, 1, 0, 1) PP_RA(0, 2, 1, b_) SB();     \
+            PP_M1(a, 1, 0, 1, 1) PP_M1(a, 1, 1, 1, 1) PP_RA(1, 3, 1, b_) SB();     \
+            PP_M1(a, 0, 0, 0, 2) PP_M1(a, 0, 1, 0, 2) PP_RA(0, 2, 2, b_) SB();     \
+            PP_M1(a, 1, 0, 1, 2) PP_M1(a, 1, 1, 1, 2) PP_RA(1, 3, 2, b_) SB();     \
+            PP_M1(a, 0, 0, 0, 3) PP_M1(a, 0, 1, 0, 3) PP_RA(0, 2, 3, b_) SB();     \
+            PP_M1(a, 1, 0, 1, 3) PP_M1(a, 1, 1, 1, 3) PP_RA(1, 3, 3, b_) SB();     \
         } else {                                                                    \
-            PP_M1(WC_, 0, 0, 0) PP_RW(WN_, 0, 0, wrd) SB(); PP_M1(WC_, 0, 1, 0) PP_RW(WN_, 0, 1, wrd) SB(); \
-            PP_M1(WC_, 1, 0, 0) PP_RW(WN_, 0, 2, wrd) SB(); PP_M1(WC_, 1, 1, 0) PP_RW(WN_, 0, 3, wrd) SB(); \
-            PP_M1(WC_, 0, 0, 1) PP_RW(WN_, 1, 0, wrd) SB(); PP_M1(WC_, 0, 1, 1) PP_RW(WN_, 1, 1, wrd) SB(); \
-            PP_M1(WC_, 1, 0, 1) PP_RW(WN_, 1, 2, wrd) SB(); PP_M1(WC_, 1, 1, 1) PP_RW(WN_, 1, 3, wrd) SB(); \
+            PP_M1(WC_, 0, 0, 0, 0) PP_RA(2, 2, 0, b_) SB(); PP_M1(WC_, 0, 1, 0, 0) PP_RA(2, 2, 1, b_) SB(); \
+            PP_M1(WC_, 1, 0, 1, 0) PP_RA(2, 2, 2, b_) SB(); PP_M1(WC_, 1, 1, 1, 0) PP_RA(2, 2, 3, b_) SB(); \
+            PP_M1(WC_, 0, 0, 0, 1) PP_RW(WN_, 0, 0, wrd) SB(); PP_M1(WC_, 0, 1, 0, 1) PP_RW(WN_, 0, 1, wrd) SB(); \
+            PP_M1(WC_, 1, 0, 1, 1) PP_RW(WN_, 0, 2, wrd) SB(); PP_M1(WC_, 1, 1, 1, 1) PP_RW(WN_, 0, 3, wrd) SB(); \
+            PP_M1(WC_, 0, 0, 0, 2) PP_RW(WN_, 1, 0, wrd) SB(); PP_M1(WC_, 0, 1, 0, 2) PP_RW(WN_, 1, 1, wrd) SB(); \
+            PP_M1(WC_, 1, 0, 1, 2) PP_RW(WN_, 1, 2, wrd) SB(); PP_M1(WC_, 1, 1, 1, 2) PP_RW(WN_, 1, 3, wrd) SB(); \
         }                                                                           \
         __builtin_amdgcn_s_setprio(0);                                              \
         PP_WAIT_LGKM();                                                             \
         PP_STAMP(3)                                                                 \
         PP_BARRIER()                                                                \
         PP_STAMP(4)                                                                 \
-        if (req && !PP_KNOCK_DMA) {                                                 \
-            PP_ISSUE_A01(b_, k2.so)                                                 \
-            PP_ISSUE_A2(mr_req, b_, k2.so)                                          \
+        if (!PP_KNOCK_DMA) {                                                        \
+            PP_ISSUE_W(ws, wq)          /* W of K-tile q+3 -> the slot of K-tile q */ \
+            if (req) PP_ISSUE_A23(mr_req, b_, k2.so)                                \
         }                                                                           \
         SB();                                                                       \
         PP_STAMP(6)                                                                 \
-        if (!last) { if (MR == 3) { PP_WAIT_VM(8); } else { PP_WAIT_VM(6); } }      \
+        if (!last) { if (MR == 4) { PP_WAIT_VM(10); } else { PP_WAIT_VM(8); } }     \
         else if (!(odd_)) { PP_WAIT_VM_RT(req ? MR + mr_req + 2 : MR + 2) }         \
         else { PP_WAIT_VM_RT(req ? 2 * mr_req + 2 : 4) }                            \
         PP_STAMP(7)                                                                 \
@@ -367,17 +368,22 @@ struct Lane {
         __builtin_amdgcn_s_setprio(1);                                              \
         /* (after a block's last K-tile the reads below fetch stale bytes that nobody uses: cheaper than a branch */ \
         /*  around the MFMAs, which made hipcc keep two register assignments alive and spill) */ \
-        if constexpr (MR == 3) {                                                    \
-            PP_MF4(WC_, 3) SB();                                                    \
-            PP_M1(WC_, 2, 0, 0) PP_RA(0, 0, (b_) ^ 1) SB(); PP_M1(WC_, 2, 1, 0) PP_RA(0, 1, (b_) ^ 1) SB(); \
-            PP_M1(WC_, 2, 0, 1) PP_RA(0, 2, (b_) ^ 1) SB(); PP_M1(WC_, 2, 1, 1) PP_RA(0, 3, (b_) ^ 1) SB(); \
-            PP_M1(WC_, 2, 0, 2) PP_RA(1, 0, (b_) ^ 1) SB(); PP_M1(WC_, 2, 1, 2) PP_RA(1, 1, (b_) ^ 1) SB(); \
-            PP_M1(WC_, 2, 0, 3) PP_RA(1, 2, (b_) ^ 1) SB(); PP_M1(WC_, 2, 1, 3) PP_RA(1, 3, (b_) ^ 1) SB(); \
+        if constexpr (MR == 4) {                                                    \
+            PP_M1(a, 2, 0, 0, 0)                          PP_M1(a, 2, 1, 0, 0) PP_RA(0, 0, 0, (b_) ^ 1) SB(); \
+            PP_M1(a, 3, 0, 1, 0) PP_RW(a, 0, 0, wrd) SB(); PP_M1(a, 3, 1, 1, 0) PP_RA(1, 1, 0, (b_) ^ 1) SB(); \
+            PP_M1(a, 2, 0, 0, 1) PP_RW(a, 1, 0, wrd) SB(); PP_M1(a, 2, 1, 0, 1) PP_RA(0, 0, 1, (b_) ^ 1) SB(); \
+            PP_M1(a, 3, 0, 1, 1) PP_RW(a, 0, 1, wrd) SB(); PP_M1(a, 3, 1, 1, 1) PP_RA(1, 1, 1, (b_) ^ 1) SB(); \
+            PP_M1(a, 2, 0, 0, 2) PP_RW(a, 1, 1, wrd) SB(); PP_M1(a, 2, 1, 0, 2) PP_RA(0, 0, 2, (b_) ^ 1) SB(); \
+            PP_M1(a, 3, 0, 1, 2) PP_RW(a, 0, 2, wrd) SB(); PP_M1(a, 3, 1, 1, 2) PP_RA(1, 1, 2, (b_) ^ 1) SB(); \
+            PP_M1(a, 2, 0, 0, 3) PP_RW(a, 1, 2, wrd) SB(); PP_M1(a, 2, 1, 0, 3) PP_RA(0, 0, 3, (b_) ^ 1) SB(); \
+            PP_M1(a, 3, 0, 1, 3) PP_RW(a, 0, 3, wrd) SB(); PP_M1(a, 3, 1, 1, 3) PP_RA(1, 1, 3, (b_) ^ 1) SB(); \
+            PP_RW(a, 1, 3, wrd) SB();                                               \
         } else {                                                                    \
-            PP_M1(WC_, 0, 0, 2) PP_RA(0, 0, (b_) ^ 1) SB(); PP_M1(WC_, 0, 1, 2) PP_RA(0, 1, (b_) ^ 1) SB(); \
-            PP_M1(WC_, 1, 0, 2) PP_RA(1, 0, (b_) ^ 1) SB(); PP_M1(WC_, 1, 1, 2) PP_RA(1, 1, (b_) ^ 1) SB(); \
-            PP_M1(WC_, 0, 0, 3) PP_RA(0, 2, (b_) ^ 1) SB(); PP_M1(WC_, 0, 1, 3) PP_RA(0, 3, (b_) ^ 1) SB(); \
-            PP_M1(WC_, 1, 0, 3) PP_RA(1, 2, (b_) ^ 1) SB(); PP_M1(WC_, 1, 1, 3) PP_RA(1, 3, (b_) ^ 1) SB(); \
+            PP_M1(WC_, 0, 0, 0, 3) PP_M1(WC_, 0, 1, 0, 3) PP_M1(WC_, 1, 0, 1, 3) PP_M1(WC_, 1, 1, 1, 3) \
+            PP_M1(WC_, 2, 0, 2, 0) PP_RA(0, 0, 0, (b_) ^ 1) SB(); PP_M1(WC_, 2, 1, 2, 0) PP_RA(0, 0, 1, (b_) ^ 1) SB(); \
+            PP_M1(WC_, 2, 0, 2, 1) PP_RA(0, 0, 2, (b_) ^ 1) SB(); PP_M1(WC_, 2, 1, 2, 1) PP_RA(0, 0, 3, (b_) ^ 1) SB(); \
+            PP_M1(WC_, 2, 0, 2, 2) PP_RA(1, 1, 0, (b_) ^ 1) SB(); PP_M1(WC_, 2, 1, 2, 2) PP_RA(1, 1, 1, (b_) ^ 1) SB(); \
+            PP_M1(WC_, 2, 0, 2, 3) PP_RA(1, 1, 2, (b_) ^ 1) SB(); PP_M1(WC_, 2, 1, 2, 3) PP_RA(1, 1, 3, (b_) ^ 1) SB(); \
         }                                                                           \
         __builtin_amdgcn_s_setprio(0);                                              \
         PP_WAIT_LGKM();                                                             \
@@ -397,8 +403,8 @@ struct Lane {
 // by pool_finalize (mean = shift + scale*S1/n, std = |scale|*sqrt((S2 - S1^2/n)/(n-1)) with the totals and
 // the difference taken in fp64); r >= 0 keeps the cancellation in S2 - S1^2/n mild (relative error of the
 // variance ~1e-7*(1 + mean^2/var)), far inside this bf16 path's 1e-2 bar.
-// v0 / v1: the accumulators of this wave's two 32-channel columns for the group at compact row row_g
-// (bias already inside: the accumulators start at it).
+// v0 / v1: this wave's two accumulators for the group at compact row row_g -- the lane's channels col0 and
+// col0 + 1 (bias already inside: the accumulators start at it).
 // Returns true when the group lay inside one utterance.
 // RAGGED is a template parameter and the utterance index is kept provably wave-uniform on purpose: with
 // a run-time "offsets ? load : multiply" hipcc emitted VECTOR loads of the offsets followed by
@@ -435,8 +441,7 @@ __device__ __forceinline__ bool pool_raw_pair(const TdnnArgs& a, const f32x16& v
         }
         const float s1a = add_halves(p1a.x + p1a.y), s2a = add_halves(p2a.x + p2a.y);
         const float s1b = add_halves(p1b.x + p1b.y), s2b = add_halves(p2b.x + p2b.y);
-        store_partial(prs, ld, grp + pc.u, h, col0, s1a, s2a);
-        store_partial(prs, ld, grp + pc.u, h, col0 + 32, s1b, s2b);
+        store_partial2(prs, ld, grp + pc.u, h, col0, s1a, s2a, s1b, s2b);
         return true;
     }
     for (int u = pc.u; u < m.n_utts; u = __builtin_amdgcn_readfirstlane(u + 1)) {   // the group straddles utterances
@@ -463,47 +468,39 @@ __device__ __forceinline__ bool pool_raw_pair(const TdnnArgs& a, const f32x16& v
         s2a = add_halves(s2a);
         s1b = add_halves(s1b);
         s2b = add_halves(s2b);
-        store_partial(prs, ld, grp + u, h, col0, s1a, s2a);
-        store_partial(prs, ld, grp + u, h, col0 + 32, s1b, s2b);
+        store_partial2(prs, ld, grp + u, h, col0, s1a, s2a, s1b, s2b);
     }
     return false;
 }
+
+// epilogue constants of a lane's two channels (n0 + 64*wc + 2r, +1), in registers for the whole launch
+struct Consts {
+    float bi0, bi1, sc0, sc1, sh0, sh1;
+};
 
 // One tile: K loop, request of the next tile's first K-tiles, epilogue.
 template <int MR, bool POOL>
 __device__ __forceinline__ void process_tile(const TdnnArgs& a, char* smem, Stream& st, const Lane& ln,
                                              const Tile& t, const Tile& nxt, bool has_next, bool first, int n0, int nk,
-                                             PoolCur& pc, float bi0, float bi1) {
+                                             PoolCur& pc, const Consts& cs) {
     // source rows of the NEXT tile (its first K-tiles are requested during this tile's last two): worked out
     // here, before the accumulators exist, and parked in four registers
     Rows rows_next = st.cur;
     if (has_next) set_rows(a, nxt, ln.grp, st, rows_next);
-    // the accumulators start at the bias: of their lane's channel (pooling variant: channel on the lane), or of
-    // each register's channel (store variant: 16 channels per lane and column, from the LDS copy)
-    f32x16 acc00, acc01, acc10, acc11, acc20, acc21;
-    if constexpr (POOL) {
+    // the accumulators start at the bias of their lane's channel
+    f32x16 acc00, acc01, acc10, acc11, acc20, acc21, acc30, acc31;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            acc00[e] = bi0; acc01[e] = bi1; acc10[e] = bi0; acc11[e] = bi1;
-            acc20[e] = bi0; acc21[e] = bi1;
-        }
-    } else {
-        const char* cb = smem + kConstOff + (ln.wc * 64 + 4 * ln.h) * 4;
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-            const float4 b0 = *reinterpret_cast<const float4*>(cb + gq * 32);
-            const float4 b1 = *reinterpret_cast<const float4*>(cb + 128 + gq * 32);
-            acc00[4 * gq] = b0.x; acc00[4 * gq + 1] = b0.y; acc00[4 * gq + 2] = b0.z; acc00[4 * gq + 3] = b0.w;
-            acc01[4 * gq] = b1.x; acc01[4 * gq + 1] = b1.y; acc01[4 * gq + 2] = b1.z; acc01[4 * gq + 3] = b1.w;
-        }
-        acc10 = acc00; acc20 = acc00;
-        acc11 = acc01; acc21 = acc01;
+    for (int e = 0; e < 16; ++e) {
+        acc00[e] = cs.bi0; acc01[e] = cs.bi1; acc10[e] = cs.bi0; acc11[e] = cs.bi1;
+        acc20[e] = cs.bi0; acc21[e] = cs.bi1; acc30[e] = cs.bi0; acc31[e] = cs.bi1;
     }
-    // W fragments, two sets: K-tiles of buffer 0 multiply from set a while set b is filled, and vice versa
+    // W fragments, two sets: K-tiles in activation buffer 0 multiply from set a while set b is filled, and vice versa
     float4 wa0_0, wa0_1, wa0_2, wa0_3, wa1_0, wa1_1, wa1_2, wa1_3;
     float4 wb0_0, wb0_1, wb0_2, wb0_3, wb1_0, wb1_1, wb1_2, wb1_3;
-    float4 af0_0, af0_1, af0_2, af0_3, af1_0, af1_1, af1_2, af1_3;     // acc rows 0,1 (read during the previous mfma 1)
-    float4 af2_0, af2_1, af2_2, af2_3;                                 // acc row 2 (read during mfma 0)
+    // activation fragments: sets 0, 1 = acc rows 0, 1 (read during the previous mfma 1) and, in a 4-row tile, acc
+    // rows 2, 3 after them (read during mfma 0 into the same registers); set 2 = acc row 2 of a 3-row tile
+    float4 af0_0, af0_1, af0_2, af0_3, af1_0, af1_1, af1_2, af1_3;
+    float4 af2_0, af2_1, af2_2, af2_3;
 #ifdef XVEC_DIAG
     unsigned long long dsum[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long dprev, dstart;
@@ -522,14 +519,14 @@ __device__ __forceinline__ void process_tile(const TdnnArgs& a, char* smem, Stre
     // A block's first tile waits for its first K-tile (requested by the kernel prologue; its pieces are older
     // than the MR+4 of K-tile 1); later tiles find it in LDS, confirmed by the previous tile's last K-tiles.
     if (first) {
-        if (MR == 3) { PP_WAIT_VM(7); } else { PP_WAIT_VM(6); }
+        if (MR == 4) { PP_WAIT_VM(8); } else { PP_WAIT_VM(7); }
         PP_BARRIER()
     }
     // acc rows 0,1 and the W fragments of K-tile 0: the only fragments read outside an MFMA segment (the previous
     // tile's last MFMA segments fetched them too, but keeping them in registers across the epilogue costs it 64
     // VGPRs)
-    PP_RA(0, 0, 0) PP_RA(0, 1, 0) PP_RA(0, 2, 0) PP_RA(0, 3, 0)
-    PP_RA(1, 0, 0) PP_RA(1, 1, 0) PP_RA(1, 2, 0) PP_RA(1, 3, 0)
+    PP_RA(0, 0, 0, 0) PP_RA(0, 0, 1, 0) PP_RA(0, 0, 2, 0) PP_RA(0, 0, 3, 0)
+    PP_RA(1, 1, 0, 0) PP_RA(1, 1, 1, 0) PP_RA(1, 1, 2, 0) PP_RA(1, 1, 3, 0)
     int ws = st.ws;
     {
         const unsigned w0 = ln.w_rd + ws * kWBytes;
@@ -537,7 +534,7 @@ __device__ __forceinline__ void process_tile(const TdnnArgs& a, char* smem, Stre
         PP_RW(a, 1, 0, w0) PP_RW(a, 1, 1, w0) PP_RW(a, 1, 2, w0) PP_RW(a, 1, 3, w0)
     }
     PP_WAIT_LGKM();
-    // Their slots are the first ones the loop refills (load 0 of K-tile 0 requests K-tile 2 into them), and the
+    // Their slots are the first ones the loop refills (K-tile 0 requests W of K-tile 3 and rows of K-tile 2 into them), and the
     // waves of a group leave the epilogue at different times: every wave must have read them before any wave
     // may request.  (Deferring that one request instead costs a branch in the loop, and with it hipcc's
     // register assignment: 160 spilled registers.)
@@ -574,46 +571,36 @@ __device__ __forceinline__ void process_tile(const TdnnArgs& a, char* smem, Stre
 
     const int64_t row0 = t.m0 + ln.grp * 32 * MR;
     if constexpr (PP_KNOCK_EPI) {
-        asm volatile("" ::"v"(acc00), "v"(acc01), "v"(acc10), "v"(acc11), "v"(acc20), "v"(acc21));
+        asm volatile("" ::"v"(acc00), "v"(acc01), "v"(acc10), "v"(acc11), "v"(acc20), "v"(acc21), "v"(acc30), "v"(acc31));
     } else if constexpr (!POOL) {
+        // ReLU + folded BatchNorm (tdnn_layer.py:30-39); the lane's two channels are adjacent (pack.hip), so one
+        // v_cvt_pk_bf16_f32 makes the dword of column 2r and a store instruction writes two whole 128-byte row
+        // segments (lane halves = rows 4 apart).  Element e of an accumulator = frame (e&3) + 8*(e>>2) + 4*h.
+        typedef float f32x2v __attribute__((ext_vector_type(2)));
         const __amdgpu_buffer_rsrc_t yrsrc = make_rsrc(static_cast<char*>(a.Y) + (t.m0 * (int64_t)a.ldy + n0) * 2);
-        const int y_voff = (ln.r * a.ldy + ln.wc * 64 + 8 * ln.h) * 2;
-        const char* cst = smem + kConstOff + (ln.wc * 64 + 4 * ln.h) * 4;
-#define PP_STORE(i_, j_)                                                                               \
-        if constexpr (MR > i_) {                                                                       \
-            if (row0 + 32 * i_ < t.valid_end)                                                             \
-                store_acc(acc##i_##j_, sc, sh, yrsrc, y_voff, (ln.grp * 32 * MR + 32 * i_) * a.ldy * 2 + 64 * j_); \
+        const int y_voff = (4 * ln.h * a.ldy + ln.wc * 64 + 2 * ln.r) * 2;
+#define PP_STORE(i_)                                                                                   \
+        if (MR > i_ && row0 + 32 * i_ < t.valid_end) {                                                    \
+            _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                              \
+                const float v0 = fmaf(fmaxf(acc##i_##0[e], 0.f), cs.sc0, cs.sh0);                         \
+                const float v1 = fmaf(fmaxf(acc##i_##1[e], 0.f), cs.sc1, cs.sh1);                         \
+                const unsigned pk = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{v0, v1}, bf16x2)); \
+                __builtin_amdgcn_raw_buffer_store_b32(pk, yrsrc, y_voff,                                  \
+                                                      (ln.grp * 32 * MR + 32 * i_ + (e & 3) + 8 * (e >> 2)) * a.ldy * 2, 0); \
+            }                                                                                             \
         }
-        {
-            float4 sc[4], sh[4];
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                sc[gq] = *reinterpret_cast<const float4*>(cst + 1024 + gq * 32);
-                sh[gq] = *reinterpret_cast<const float4*>(cst + 2048 + gq * 32);
-            }
-            PP_STORE(0, 0) PP_STORE(1, 0) PP_STORE(2, 0)
-        }
-        {
-            float4 sc[4], sh[4];
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                sc[gq] = *reinterpret_cast<const float4*>(cst + 128 + 1024 + gq * 32);
-                sh[gq] = *reinterpret_cast<const float4*>(cst + 128 + 2048 + gq * 32);
-            }
-            PP_STORE(0, 1) PP_STORE(1, 1) PP_STORE(2, 1)
-        }
+        PP_STORE(0) PP_STORE(1) PP_STORE(2) PP_STORE(3)
 #undef PP_STORE
     } else {
-        const int col0 = n0 + ln.wc * 64 + ln.r;
+        const int col0 = n0 + ln.wc * 64 + 2 * ln.r;
 #define PP_POOL(RG_, i_)                                                                               \
-        if constexpr (MR > i_) {                                                                       \
-            if (row0 + 32 * i_ < t.valid_end)                                                             \
-                pool_raw_pair<RG_>(a, acc##i_##0, acc##i_##1, row0 + 32 * i_, ln.h, col0, pc);            \
+        if (MR > i_ && row0 + 32 * i_ < t.valid_end) {                                                    \
+            pool_raw_pair<RG_>(a, acc##i_##0, acc##i_##1, row0 + 32 * i_, ln.h, col0, pc);                \
         }
         if (a.out_map.offsets == nullptr) {
-            PP_POOL(false, 0) PP_POOL(false, 1) PP_POOL(false, 2)
+            PP_POOL(false, 0) PP_POOL(false, 1) PP_POOL(false, 2) PP_POOL(false, 3)
         } else {
-            PP_POOL(true, 0) PP_POOL(true, 1) PP_POOL(true, 2)
+            PP_POOL(true, 0) PP_POOL(true, 1) PP_POOL(true, 2) PP_POOL(true, 3)
         }
 #undef PP_POOL
     }
@@ -658,20 +645,19 @@ __global__ __launch_bounds__(kThreads, 2) void tdnn_pp_kernel(const TdnnArgs a) 
         ln.k2 = ((4 + ln.h) ^ sw) << 4;
         ln.k3 = ((6 + ln.h) ^ sw) << 4;
     }
-    ln.a_rd = ln.grp * 3 * kAccRowB + ln.rd;
+    ln.a_rd = ln.grp * 4 * kAccRowB + ln.rd;
     ln.w_rd = kWOff + ln.wc * 2 * kAccRowB + ln.rd;
 
-    // per-channel constants of the block's column -> LDS (store variant reads them per register)
-    if (tid < 192) {
-        const int arr = tid >> 6, c4 = (tid & 63) * 4;
-        const float* src = arr == 0 ? a.bias : arr == 1 ? a.scale : a.shift;
-        *reinterpret_cast<float4*>(smem + kConstOff + arr * 1024 + c4 * 4) = *reinterpret_cast<const float4*>(src + n0 + c4);
-    }
-    float bi0 = 0.f, bi1 = 0.f;
-    if (POOL) {
-        const int c = n0 + ln.wc * 64 + ln.r;
-        bi0 = a.bias[c];
-        bi1 = a.bias[c + 32];
+    Consts cs;
+    {
+        const int c = n0 + ln.wc * 64 + 2 * ln.r;
+        const float2 b2 = *reinterpret_cast<const float2*>(a.bias + c);
+        cs.bi0 = b2.x; cs.bi1 = b2.y;
+        cs.sc0 = cs.sc1 = cs.sh0 = cs.sh1 = 0.f;
+        if (!POOL) {
+            const float2 s2 = *reinterpret_cast<const float2*>(a.scale + c), h2 = *reinterpret_cast<const float2*>(a.shift + c);
+            cs.sc0 = s2.x; cs.sc1 = s2.y; cs.sh0 = h2.x; cs.sh1 = h2.y;
+        }
     }
 
     // DMA map of this wave: piece row = lane >> 3 (8 rows per piece), LDS position lane & 7 holds the
@@ -682,7 +668,7 @@ __global__ __launch_bounds__(kThreads, 2) void tdnn_pp_kernel(const TdnnArgs a) 
         const int rr = ln.wc * 8 + prow;                                  // A: row within the 32-frame acc row
         st.row_in_group = rr;
         st.a_chunk = (ppos ^ ((rr >> 1) & 7)) * 16;
-        st.lds_a = (unsigned)(unsigned long long)(lds_ptr)(smem) + ln.grp * 3 * kAccRowB + ln.wc * 1024;
+        st.lds_a = (unsigned)(unsigned long long)(lds_ptr)(smem) + ln.grp * 4 * kAccRowB + ln.wc * 1024;
         const int wr = ln.wave * 8 + prow;                                // W: channel row of piece t = wr + 64*t
         const int w_chunk = (ppos ^ ((wr >> 1) & 7)) * 16;                // ((wr + 64t) >> 1) & 7 is the same for every t
         st.lds_w = (unsigned)(unsigned long long)(lds_ptr)(smem) + kWOff + ln.wave * 1024;
@@ -698,35 +684,34 @@ __global__ __launch_bounds__(kThreads, 2) void tdnn_pp_kernel(const TdnnArgs a) 
         pc.u = 0;
         pc.end = 0;
 
-        // tiles of this block: n units cut into tiles of 3 units and at most two of 2 (n = 1: one tile of 2 whose
-        // second unit lies past the range and is masked)
+        // tiles of this block: n units cut into ceil(n/4) tiles of 3 or 4 units, as equal as possible
+        // (n = 1, 2, 5 cannot be: the last tile then computes rows past the range and masks them)
         const int n = (int)(u_end - u_begin);
         if (n <= 0) return;
-        const int n2 = n % 3 == 0 ? 0 : n % 3 == 2 ? 1 : (n >= 4 ? 2 : 1);
-        const int n3 = n >= 2 * n2 ? (n - 2 * n2) / 3 : 0;
-        const int nt = n3 + n2;
+        int nt = (n + 3) / 4;
+        int base = n / nt, extra = n % nt;
+        if (base < 3) { base = 3; extra = 0; nt = (n + 2) / 3; }
         const int64_t range_end = u_end * 64;
 
         auto tile_at = [&](int idx, int64_t m0) {
             Tile t;
             t.m0 = m0;
-            t.mr = idx < n3 ? 3 : 2;
+            t.mr = idx < extra ? base + 1 : base;
             t.valid_end = range_end;
             return t;
         };
         Tile cur = tile_at(0, u_begin * 64);
         if (POOL) pc = pool_cursor(a, cur.m0 + ln.grp * 32 * cur.mr);
         set_rows(a, cur, ln.grp, st, st.cur);
-        __syncthreads();                                   // constants visible; nobody reads LDS buffers yet
         issue_head(a, st, cur.mr);
         for (int idx = 0; idx < nt; ++idx) {
             const bool has_next = idx + 1 < nt;
             Tile nxt = cur;
             if (has_next) nxt = tile_at(idx + 1, cur.m0 + 64 * cur.mr);
-            if (cur.mr == 3)
-                process_tile<3, POOL>(a, smem, st, ln, cur, nxt, has_next, idx == 0, n0, nk, pc, bi0, bi1);
+            if (cur.mr == 4)
+                process_tile<4, POOL>(a, smem, st, ln, cur, nxt, has_next, idx == 0, n0, nk, pc, cs);
             else
-                process_tile<2, POOL>(a, smem, st, ln, cur, nxt, has_next, idx == 0, n0, nk, pc, bi0, bi1);
+                process_tile<3, POOL>(a, smem, st, ln, cur, nxt, has_next, idx == 0, n0, nk, pc, cs);
             cur = nxt;
         }
         // the weight requests wrapped round past the block's last tile: nothing may still be writing LDS at exit

@@ -74,6 +74,7 @@ __device__ __forceinline__ void dma16(const i32x4& rsrc, unsigned dst, int voff,
 // Diagnostic build only (make DIAG=1): s_memtime stamps of one wave per group, summed per segment kind.
 // slot = 16 * group + kind; kinds: 0-5 phase 0 (issue, wait, barrier, mfma, barrier, -), 6-11 phase 1
 __device__ unsigned long long g_pp_diag[2 * 512 * 32];   // [pooling variant][block][group][kind]
+__device__ unsigned long long g_pp_clk[8];               // block 0: s_memtime / s_memrealtime at entry and exit, per variant
 #define PP_STAMP(k_)                                                                               \
     {                                                                                              \
         SB();                                                                                      \
@@ -604,6 +605,12 @@ __global__ __launch_bounds__(kThreads, 2) void tdnn_pp_kernel(const TdnnArgs a) 
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
+#ifdef XVEC_DIAG
+    if (blockIdx.x == 0 && tid == 0) {
+        g_pp_clk[(POOL ? 4 : 0) + 0] = __builtin_amdgcn_s_memtime();
+        g_pp_clk[(POOL ? 4 : 0) + 1] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
     Lane ln;
     ln.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     ln.grp = ln.wave >> 2;
@@ -687,12 +694,21 @@ __global__ __launch_bounds__(kThreads, 2) void tdnn_pp_kernel(const TdnnArgs a) 
                 process_tile<3, POOL>(a, smem, st, ln, cur, nxt, has_next, idx == 0, n0, nk, pc, cs);
             cur = nxt;
         }
+#ifdef XVEC_DIAG
+        if (blockIdx.x == 0 && tid == 0) {
+            g_pp_clk[(POOL ? 4 : 0) + 2] = __builtin_amdgcn_s_memtime();
+            g_pp_clk[(POOL ? 4 : 0) + 3] = __builtin_amdgcn_s_memrealtime();
+        }
+#endif
     }
 }
 
 }  // namespace pp
 
 #ifdef XVEC_DIAG
+extern "C" int xvec_pp_clk_read(unsigned long long* host) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(pp::g_pp_clk), 8 * 8);
+}
 extern "C" int xvec_pp_diag_read(unsigned long long* host, int n_words, int reset) {
     hipError_t e = hipMemcpyFromSymbol(host, HIP_SYMBOL(pp::g_pp_diag), (size_t)n_words * 8);
     if (e == hipSuccess && reset) e = hipMemset(nullptr, 0, 0);

@@ -21,12 +21,11 @@
 //   * persistent: a block owns a contiguous range of 64-frame units of one 256-channel column and
 //     cuts it into tiles of 3 or 4 units, as equal as possible (a partial round of fixed 256-row
 //     tiles would idle a quarter of the chip at B=256: 584 tiles over 256 CUs).
-//   * store epilogue: the accumulators hold CHANNELS in their registers and frames on the lanes
-//     (weights are the MFMA A operand), so a lane owns 4 consecutive channels per register group;
-//     bias + ReLU + folded BatchNorm from per-channel constants kept in LDS, packed to bf16,
-//     v_permlane32_swap pairs the lane halves and every store is 16 bytes.
-//     Pooling epilogue (layer 5): operands swapped (frames in the registers, channel on the lane),
-//     so the per-(32-frame group, utterance) mean / M2 partials are register sums (pool_group).
+//   * epilogues: frames in the accumulator's registers, the channel on the lane, and a lane's two accumulators
+//     hold ADJACENT channels (a row permutation of the packed weights, pack.hip); bias / scale / shift of those
+//     two channels stay in registers.  Store variant: ReLU + folded BatchNorm, v_cvt_pk_bf16_f32 joins the two
+//     columns and a store instruction writes two whole 128-byte row segments.  Pooling variant (layer 5): raw
+//     sums (sum r, sum r^2) of r = relu(z + bias) per (32-frame group, utterance), one 8-byte pair per lane.
 // The next tile's first K-tiles are requested before the epilogue, so the DMA flies under it.
 #include "tdnn_common.h"
 

@@ -278,9 +278,36 @@ class XVectorModel(nn.Module):
         arr = (C.c_int32 * B)(*lengths)
         return arr, lengths
 
+    #: utterances per library call (xvec_hip.h: the pinned offsets ring holds 65 535 + 1 entries)
+    MAX_UTTS_PER_CALL = 65535
+
+    def _max_frames_per_call(self) -> Optional[int]:
+        """Frames (B*T, padding included) one library call may carry, or None.  Only bf16x3 has such a limit: its two
+        bf16 planes are addressed with 30-bit offsets (xvec_api.hip: plane = rows_alloc * hidden_pad * 2 bytes)."""
+        if self.precision != "bf16x3":
+            return None
+        hidden_pad = -(-max(self.hparams["hidden_size"], 1) // 128) * 128
+        return (0x3FFFFFFF // (hidden_pad * 2)) - 1024            # rows_alloc = frames rounded up to 128, + 264
+
+    @staticmethod
+    def _call_ranges(B: int, T: int, max_frames: Optional[int], max_utts: int):
+        """[lo, hi) utterance ranges of a [B, T, .] batch such that no range exceeds `max_frames` padded frames or
+        `max_utts` utterances (a service handing over more than one call can hold gets several calls, not an error)."""
+        per = max_utts if max_frames is None else min(max_utts, max_frames // T)
+        if per < 1:
+            raise ValueError(f"one utterance of {T} frames exceeds the {max_frames} frames a call can hold in this precision")
+        return [(lo, min(lo + per, B)) for lo in range(0, B, per)]
+
     def _run(self, x: torch.Tensor, mode: int, lengths=None, workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
         x = self._prep_input(x, "XVectorModel")
         B, T, Cin = x.shape
+        if workspace is None:
+            ranges = self._call_ranges(B, T, self._max_frames_per_call(), self.MAX_UTTS_PER_CALL)
+            if len(ranges) > 1:
+                if lengths is not None and torch.is_tensor(lengths):
+                    lengths = lengths.detach().cpu().tolist()
+                return torch.cat([self._run(x[lo:hi], mode, None if lengths is None else list(lengths[lo:hi]))
+                                  for lo, hi in ranges], 0)
         if Cin != self.hparams["input_size"]:
             raise ValueError(f"expected {self.hparams['input_size']} input channels, got {Cin}")
         if T <= TOTAL_CONTEXT:

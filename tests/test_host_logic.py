@@ -245,3 +245,20 @@ def test_checkpoint_with_unimportable_lightning_classes(tmp_path, synth):
         assert torch.equal(m.state_dict()[k], v), k
     # overrides win over stored hyper-parameters (Lightning's load_from_checkpoint(**kwargs))
     assert xa.XVectorModel.load_from_checkpoint(path, x_vec_extract_layer=6).x_vec_extract_layer == 6
+
+
+def test_call_ranges_split_a_batch_that_one_call_cannot_hold():
+    """bf16x3 addresses its planes with 30-bit offsets (~1 M frames per call); the host splits the
+    batch instead of surfacing XVEC_ERR_ARG.  The same for more utterances than the library's offsets ring holds."""
+    import xvector_amd as xa
+    R = xa.XVectorModel._call_ranges
+    assert R(256, 300, None, 65535) == [(0, 256)]
+    assert R(256, 300, 1_000_000, 65535) == [(0, 256)]
+    assert R(5000, 300, 1_000_000, 65535) == [(0, 3333), (3333, 5000)]
+    assert R(70000, 20, None, 65535) == [(0, 65535), (65535, 70000)]
+    assert R(7, 400, 1000, 65535) == [(0, 2), (2, 4), (4, 6), (6, 7)]
+    with pytest.raises(ValueError, match="exceeds"):
+        R(2, 2000, 1000, 65535)
+    m = xa.XVectorModel(precision="bf16x3")
+    assert 1_000_000 < m._max_frames_per_call() < (1 << 20)
+    assert xa.XVectorModel(precision="bf16")._max_frames_per_call() is None

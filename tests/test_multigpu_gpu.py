@@ -210,3 +210,30 @@ def test_graphed_path_owns_its_scratch(gpu_model, synth):
     assert torch.equal(out, eager)
     assert all(bool((c == 7.0).all()) for c in canaries)
     del before
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["bf16x3", "fp32"])
+def test_batches_larger_than_one_call_are_split(precision, monkeypatch):
+    """A batch that exceeds what one library call can carry (bf16x3: 30-bit plane offsets; any mode: 65 535
+    utterances) is cut into several calls by the host; results equal the unsplit call's to rounding."""
+    import numpy as np
+    import torch
+    import xvector_amd as xa
+    dev = torch.device("cuda:0")
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in xa.synth.make_state_dict(seed=42).items()}
+    m = xa.XVectorModel(precision=precision)
+    m.load_state_dict(sd)
+    m = m.to(dev).eval()
+    x = torch.from_numpy(xa.synth.make_mfcc(11, 120, seed=5)).to(dev)
+    lens = [120, 60, 90, 33, 120, 47, 101, 120, 15 + 1, 80, 64]
+    whole, whole_r, whole_logits = m.extract_x_vec(x), m.extract_x_vec(x, lengths=lens), m(x)
+    monkeypatch.setattr(xa.XVectorModel, "MAX_UTTS_PER_CALL", 4)
+    if precision == "bf16x3":
+        monkeypatch.setattr(xa.XVectorModel, "_max_frames_per_call", lambda self: 3 * 120)
+    split, split_r = m.extract_x_vec(x), m.extract_x_vec(x, lengths=lens)
+    # same arithmetic per frame; the pooling partials are cut at 32-row groups of the CALL's row layout, so the
+    # fp32 summation order over an utterance's frames differs between the two: rounding-level differences only
+    def same(a, b):
+        return a.shape == b.shape and float((a - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max()))
+    assert same(split, whole) and same(split_r, whole_r) and same(m(x), whole_logits)

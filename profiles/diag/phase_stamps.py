@@ -12,7 +12,7 @@ m = xa.XVectorModel(precision=prec); m.load_state_dict(sd); m = m.to("cuda:0")
 layer = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 T_in = [300, 296, 292, 286, 286][layer]
 x = torch.randn(256, T_in, 24 if layer == 0 else 512, device="cuda:0")
-for _ in range(3):
+for _ in range(int(os.environ.get("STAMP_ITERS", "3"))):      # STAMP_ITERS=200: past the clock ramp of a cold chip
     if layer == 4 and len(sys.argv) > 3:      # whole path: the stamps left are layer 5's fused-pooling launch
         y = m.extract_x_vec(torch.randn(256, 300, 24, device="cuda:0"))
     else:
@@ -29,6 +29,9 @@ print(f"{prec} layer {layer + 1}: blocks {len(d)}  groups/block {d[:,2].mean():.
 print(f"block lifetime cycles: mean {total.mean():.0f} max {total.max():.0f}")
 print(f"K-loop per tile: {(d[:,3]/tiles).mean():.0f}   epilogue per tile: {(d[:,4]/tiles).mean():.0f}   "
       f"outside (prologue, tile switch, waits): {((total - d[:,3] - d[:,4])/tiles).mean():.0f} per tile")
+real = d[:, 7] - d[:, 6]
+print(f"core clock during the launch (s_memtime cycles per s_memrealtime tick of 10 ns): {np.median(total / (real / 100.0)) / 1e3:.3f} GHz "
+      f"(block lifetime {np.median(real) / 100.0:.1f} us)")
 print(f"shares: loop {d[:,3].sum()/total.sum()*100:.1f}%  epilogue {d[:,4].sum()/total.sum()*100:.1f}%  other {(1-(d[:,3].sum()+d[:,4].sum())/total.sum())*100:.1f}%")
 # first-slot (b < grid/2) vs second-slot blocks of a CU pair: start/end relative to the earliest start
 h = len(d) // 2

@@ -562,7 +562,7 @@ template <int GUARD, bool POOL, bool STORE, bool INBF, bool OUTBF, bool X3>
 __global__ __launch_bounds__(256, 2) void tdnn_kernel(const TdnnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
 #ifdef XVEC_DIAG
-    const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
+    const unsigned long long t_entry = __builtin_amdgcn_s_memtime(), r_entry = __builtin_amdgcn_s_memrealtime();
     if (threadIdx.x == 0 && blockIdx.x < 8192) { g_diag[blockIdx.x * 8 + 3] = 0; g_diag[blockIdx.x * 8 + 4] = 0; g_diag[blockIdx.x * 8 + 5] = 0; }
 #endif
     // logical id -> (row range p, channel column j); the n_tiles columns of one range are
@@ -655,6 +655,8 @@ __global__ __launch_bounds__(256, 2) void tdnn_kernel(const TdnnArgs a) {
         d[0] = t_entry;
         d[1] = __builtin_amdgcn_s_memtime();
         d[2] = (unsigned long long)(g_end - g_begin);
+        d[6] = r_entry;                              // 100 MHz reference clock at entry / exit: core clock of the launch
+        d[7] = __builtin_amdgcn_s_memrealtime();
     }
 #endif
 }

@@ -52,6 +52,19 @@ def test_sharded_extraction_world2(tmp_path, n_total, ragged):
         assert torch.allclose(got, want, rtol=0, atol=0), f"rank {r} differs"
 
 
+@pytest.mark.parametrize("n_total,ragged", [(23, False), (3, False), (23, True)])
+def test_sharded_extraction_world4(tmp_path, n_total, ragged):
+    """Four ranks (half the 8-GPU node of BASELINE configs[3]): uneven shards (6, 6, 6, 5), a rank with no
+    utterance at all (3 over 4 ranks), and the frame-balanced ragged split."""
+    port = 33500 + os.getpid() % 2000 + n_total + (50 if ragged else 0)
+    mp.spawn(_worker, args=(4, port, n_total, ragged, str(tmp_path)), nprocs=4, join=True)
+    want = _fake_extract(_make_batch(0, n_total))
+    for r in range(4):
+        got = torch.load(os.path.join(str(tmp_path), f"r{r}.pt"))
+        assert got.shape == want.shape
+        assert torch.allclose(got, want, rtol=0, atol=0), f"rank {r} differs"
+
+
 def test_single_process_is_identity():
     sys.path.insert(0, ROOT)
     from xvector_amd import extract

@@ -346,7 +346,7 @@ def main():
         peak = {"fp32": FP32_MFMA_PEAK, "bf16": BF16_MFMA_PEAK, "bf16x3": BF16_MFMA_PEAK / 3}[args.dtype]
         # bf16 at this batch size runs the 256-channel ping-pong mapping (csrc/tdnn_pp.hip); smaller batches and
         # bf16x3 the 128x128 kernel (csrc/tdnn_layer.hip)
-        pp16 = args.dtype == "bf16" and B * (T - 14) >= 3 * 64 * 128
+        pp16 = args.dtype == "bf16" and 5 * -(-B * (T - 14) // 64) >= 11 * 128      # run_tdnn's dispatch rule
         dom_kernel = ("xvec::pp::tdnn_pp_kernel<false> (layers 2-4, bf16 MFMA, LDS-DMA operands)" if pp16 else
                       "xvec::tdnn_kernel<0,false,true,true,true,X3> (layers 2-4, bf16 MFMA"
                       + (", three products per k-step)" if args.dtype == "bf16x3" else ")") if bf else

@@ -37,7 +37,9 @@ constexpr int kAccRowB = 32 * kRowB;              // 32 frames: 4 KiB = 4 DMA pi
 constexpr int kABytes = 2 * 4 * kAccRowB;         // [group][acc row][32 frames]: 32 KiB
 constexpr int kWBytes = 256 * kRowB;              // 256 channels: 32 KiB = 32 DMA pieces
 constexpr int kBufBytes = kABytes + kWBytes;      // 64 KiB
-constexpr int kLdsBytes = 2 * kBufBytes;
+constexpr int kConstOff = 2 * kBufBytes;
+constexpr int kConstBytes = 3 * 256 * 4;          // bias | scale | shift of the block's 256 channels, natural order
+constexpr int kLdsBytes = kConstOff + kConstBytes;
 constexpr int kThreads = 512;
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -122,6 +124,7 @@ __device__ unsigned long long g_pp_clk[8];               // block 0: s_memtime /
         else if (nn_ == 9) { PP_WAIT_VM(9); }                    \
         else if (nn_ == 8) { PP_WAIT_VM(8); }                    \
         else if (nn_ == 7) { PP_WAIT_VM(7); }                    \
+        else if (nn_ == 6) { PP_WAIT_VM(6); }                    \
         else if (nn_ == 2) { PP_WAIT_VM(2); }                    \
         else if (nn_ == 1) { PP_WAIT_VM(1); }                    \
         else { PP_WAIT_VM(0); }                                  \
@@ -237,17 +240,19 @@ __device__ __forceinline__ void kstep(const TdnnArgs& a, KPos& k) {
     }
 #define PP_ISSUE_A23(MR_, b_, so_)                                                  \
     {                                                                               \
-        dma16(st.cur.xrsrc, st.lds_a + (b_) * kBufBytes + 2 * kAccRowB, st.cur.av2, so_);   \
+        if ((MR_) > 2) dma16(st.cur.xrsrc, st.lds_a + (b_) * kBufBytes + 2 * kAccRowB, st.cur.av2, so_);   \
         if ((MR_) > 3) dma16(st.cur.xrsrc, st.lds_a + (b_) * kBufBytes + 3 * kAccRowB, st.cur.av3, so_); \
     }
 
 // first K-tiles of a tile: part 1 = all of K-tile 0; part 2 = all of K-tile 1, in the K loop's request order
 // (acc rows 0,1, then W, then acc rows 2,3), which keeps the loop's counted waits uniform from the first K-tile
+template <bool POOL>
 __device__ __forceinline__ void issue_head1(const TdnnArgs& a, const Stream& st, int mr) {
     PP_ISSUE_W(0, 0)
     PP_ISSUE_A01(0, 0)
     PP_ISSUE_A23(mr, 0, 0)
 }
+template <bool POOL>
 __device__ __forceinline__ void issue_head2(const TdnnArgs& a, const Stream& st, int mr) {
     KPos k1 = {0, 0};
     kstep(a, k1);
@@ -327,20 +332,24 @@ struct Lane {
         SB();                                                                       \
         PP_WAIT_LGKM();                                                             \
         PP_STAMP(0)                                                                 \
-        if (!last) { if (MR == 4) { PP_WAIT_VM(10); } else { PP_WAIT_VM(9); } }     \
+        if (!last) { if (MR == 4) { PP_WAIT_VM(10); } else if (MR == 3) { PP_WAIT_VM(9); } else { PP_WAIT_VM(8); } } \
         else if (!(odd_)) { PP_WAIT_VM_RT(req ? MR + 6 : MR + 4) }                  \
         else { PP_WAIT_VM_RT(req ? mr_req + 6 : 0) }                                \
         PP_STAMP(1)                                                                 \
         PP_BARRIER()                                                                \
         PP_STAMP(2)                                                                 \
         __builtin_amdgcn_s_setprio(1);                                              \
+        if constexpr (MR == 2) {   /* rows 0,1, k-steps 0,1: nothing to read (no acc row 2) */ \
+            PP_MF4(0, 1, 0) SB(); PP_MF4(0, 1, 1) SB();                             \
+        } else {                                                                    \
         PP_M1(0, 0, 0) PP_RA(2, 0, b_) SB(); PP_M1(0, 1, 0) PP_RA(2, 1, b_) SB();   \
         PP_M1(1, 0, 0) PP_RA(2, 2, b_) SB(); PP_M1(1, 1, 0) PP_RA(2, 3, b_) SB();   \
+        }                                                                           \
         if constexpr (MR == 4) {                                                    \
             PP_M1(0, 0, 1) PP_RA(3, 0, b_) SB(); PP_M1(0, 1, 1) PP_RA(3, 1, b_) SB(); \
             PP_M1(1, 0, 1) PP_RA(3, 2, b_) SB(); PP_M1(1, 1, 1) PP_RA(3, 3, b_) SB(); \
             PP_MF4(0, 1, 2) SB(); PP_MF4(0, 1, 3) SB();                             \
-        } else {                                                                    \
+        } else if constexpr (MR == 3) {                                             \
             PP_MF4(0, 1, 1) SB(); PP_MF4(0, 1, 2) SB();                             \
         }                                                                           \
         __builtin_amdgcn_s_setprio(0);                                              \
@@ -354,7 +363,7 @@ struct Lane {
         }                                                                           \
         SB();                                                                       \
         PP_STAMP(6)                                                                 \
-        if (!last) { if (MR == 4) { PP_WAIT_VM(10); } else { PP_WAIT_VM(8); } }     \
+        if (!last) { if (MR == 4) { PP_WAIT_VM(10); } else if (MR == 3) { PP_WAIT_VM(8); } else { PP_WAIT_VM(6); } } \
         else if (!(odd_)) { PP_WAIT_VM_RT(req ? MR + mr_req + 2 : MR - 2) }         \
         else { PP_WAIT_VM_RT(req ? 2 * mr_req + 2 : 0) }                            \
         PP_STAMP(7)                                                                 \
@@ -362,6 +371,12 @@ struct Lane {
         PP_STAMP(8)                                                                 \
         __builtin_amdgcn_s_setprio(1);                                              \
         if constexpr (MR == 3) { PP_MF4(0, 1, 3) SB(); }                            \
+        if constexpr (MR == 2) {   /* k-steps 2,3; each read behind the last MFMA that uses the register it overwrites */ \
+            PP_M1(0, 0, 2) PP_RA(0, 0, (b_) ^ 1) SB(); PP_M1(0, 1, 2) PP_RA(0, 1, (b_) ^ 1) SB(); \
+            PP_M1(1, 0, 2) PP_RA(1, 0, (b_) ^ 1) SB(); PP_M1(1, 1, 2) PP_RA(1, 1, (b_) ^ 1) SB(); \
+            PP_M1(0, 0, 3) PP_RA(0, 2, (b_) ^ 1) SB(); PP_M1(0, 1, 3) PP_RA(0, 3, (b_) ^ 1) SB(); \
+            PP_M1(1, 0, 3) PP_RA(1, 2, (b_) ^ 1) SB(); PP_M1(1, 1, 3) PP_RA(1, 3, (b_) ^ 1) SB(); \
+        } else {                                                                    \
         /* (after a block's last K-tile these reads fetch stale bytes that nobody uses: cheaper than a branch */ \
         /*  around the MFMAs, which made hipcc keep two register assignments alive and spill) */ \
         PP_M1(2, 0, 0) PP_RA(0, 0, (b_) ^ 1) SB(); PP_M1(2, 1, 0) PP_RA(0, 1, (b_) ^ 1) SB(); \
@@ -370,6 +385,7 @@ struct Lane {
         PP_M1(2, 0, 3) PP_RA(1, 2, (b_) ^ 1) SB(); PP_M1(2, 1, 3) PP_RA(1, 3, (b_) ^ 1) SB(); \
         if constexpr (MR == 4) {                                                    \
             PP_MF2(3, 0) PP_MF2(3, 1) PP_MF2(3, 2) PP_MF2(3, 3) SB();               \
+        }                                                                           \
         }                                                                           \
         __builtin_amdgcn_s_setprio(0);                                              \
         PP_WAIT_LGKM();                                                             \
@@ -458,26 +474,26 @@ __device__ __forceinline__ bool pool_raw_pair(const TdnnArgs& a, const f32x16& v
     return false;
 }
 
-// epilogue constants of a lane's two channels (n0 + 64*wc + 2r, +1), in registers for the whole launch
-struct Consts {
-    float bi0, bi1, sc0, sc1, sh0, sh1;
-};
-
 // One tile: K loop, request of the next tile's first K-tiles, epilogue.
 template <int MR, bool POOL>
 __device__ __forceinline__ void process_tile(const TdnnArgs& a, char* smem, Stream& st, const Lane& ln,
                                              const Tile& t, const Tile& nxt, bool has_next, bool first, int n0, int nk,
-                                             PoolCur& pc, const Consts& cs) {
+                                             PoolCur& pc) {
     // source rows of the NEXT tile (its first K-tiles are requested during this tile's last two): worked out
     // here, before the accumulators exist, and parked in four registers
     Rows rows_next = st.cur;
     if (has_next) set_rows(a, nxt, ln.grp, st, rows_next);
-    // the accumulators start at the bias of their lane's channel
+    // the accumulators start at the bias of their lane's two channels (64*wc + 2r, +1 of the block's column; the
+    // constants live in a 3-KiB LDS table: six registers held across the K loop were what a third tile height cost)
+    const float* cst = reinterpret_cast<const float*>(smem + kConstOff) + ln.wc * 64 + 2 * ln.r;
     f32x16 acc00, acc01, acc10, acc11, acc20, acc21, acc30, acc31;
+    {
+        const float2 bi = *reinterpret_cast<const float2*>(cst);
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        acc00[e] = cs.bi0; acc01[e] = cs.bi1; acc10[e] = cs.bi0; acc11[e] = cs.bi1;
-        acc20[e] = cs.bi0; acc21[e] = cs.bi1; acc30[e] = cs.bi0; acc31[e] = cs.bi1;
+        for (int e = 0; e < 16; ++e) {
+            acc00[e] = bi.x; acc01[e] = bi.y; acc10[e] = bi.x; acc11[e] = bi.y;
+            acc20[e] = bi.x; acc21[e] = bi.y; acc30[e] = bi.x; acc31[e] = bi.y;
+        }
     }
     float4 wf0_0, wf0_1, wf0_2, wf0_3, wf1_0, wf1_1, wf1_2, wf1_3;
     float4 af0_0, af0_1, af0_2, af0_3, af1_0, af1_1, af1_2, af1_3;     // acc rows 0,1 (read during the previous mfma 1)
@@ -499,7 +515,7 @@ __device__ __forceinline__ void process_tile(const TdnnArgs& a, char* smem, Stre
     // A block's first tile waits for its first K-tile (requested by the kernel prologue; its pieces are older
     // than the MR+4 of K-tile 1); later tiles find it in LDS, confirmed by the previous tile's last K-tiles.
     if (first) {
-        if (MR == 4) { PP_WAIT_VM(8); } else { PP_WAIT_VM(7); }
+        if (MR == 4) { PP_WAIT_VM(8); } else if (MR == 3) { PP_WAIT_VM(7); } else { PP_WAIT_VM(6); }
         PP_BARRIER()
     }
     // acc rows 0,1 of K-tile 0: the only activation fragments read outside an MFMA segment (the previous tile's
@@ -552,11 +568,12 @@ __device__ __forceinline__ void process_tile(const TdnnArgs& a, char* smem, Stre
         typedef float f32x2v __attribute__((ext_vector_type(2)));
         const __amdgpu_buffer_rsrc_t yrsrc = make_rsrc(static_cast<char*>(a.Y) + (t.m0 * (int64_t)a.ldy + n0) * 2);
         const int y_voff = (4 * ln.h * a.ldy + ln.wc * 64 + 2 * ln.r) * 2;
+        const float2 sc = *reinterpret_cast<const float2*>(cst + 256), sh = *reinterpret_cast<const float2*>(cst + 512);
 #define PP_STORE(i_)                                                                                   \
         if (MR > i_ && row0 + 32 * i_ < t.valid_end) {                                                    \
             _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                              \
-                const float v0 = fmaf(fmaxf(acc##i_##0[e], 0.f), cs.sc0, cs.sh0);                         \
-                const float v1 = fmaf(fmaxf(acc##i_##1[e], 0.f), cs.sc1, cs.sh1);                         \
+                const float v0 = fmaf(fmaxf(acc##i_##0[e], 0.f), sc.x, sh.x);                             \
+                const float v1 = fmaf(fmaxf(acc##i_##1[e], 0.f), sc.y, sh.y);                             \
                 const unsigned pk = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{v0, v1}, bf16x2)); \
                 __builtin_amdgcn_raw_buffer_store_b32(pk, yrsrc, y_voff,                                  \
                                                       (ln.grp * 32 * MR + 32 * i_ + (e & 3) + 8 * (e >> 2)) * a.ldy * 2, 0); \
@@ -627,16 +644,11 @@ __global__ __launch_bounds__(kThreads, 2) void tdnn_pp_kernel(const TdnnArgs a) 
     ln.a_rd = ln.grp * 4 * kAccRowB + ln.rd;
     ln.w_rd = kABytes + ln.wc * 2 * kAccRowB + ln.rd;
 
-    Consts cs;
-    {
-        const int c = n0 + ln.wc * 64 + 2 * ln.r;
-        const float2 b2 = *reinterpret_cast<const float2*>(a.bias + c);
-        cs.bi0 = b2.x; cs.bi1 = b2.y;
-        cs.sc0 = cs.sc1 = cs.sh0 = cs.sh1 = 0.f;
-        if (!POOL) {
-            const float2 s2 = *reinterpret_cast<const float2*>(a.scale + c), h2 = *reinterpret_cast<const float2*>(a.shift + c);
-            cs.sc0 = s2.x; cs.sc1 = s2.y; cs.sh0 = h2.x; cs.sh1 = h2.y;
-        }
+    // per-channel constants of the block's column -> LDS
+    if (tid < 192) {
+        const int arr = tid >> 6, c4 = (tid & 63) * 4;
+        const float* src = arr == 0 ? a.bias : arr == 1 ? a.scale : a.shift;
+        *reinterpret_cast<float4*>(smem + kConstOff + arr * 1024 + c4 * 4) = *reinterpret_cast<const float4*>(src + n0 + c4);
     }
 
     // DMA map of this wave: piece row = lane >> 3 (8 rows per piece), LDS position lane & 7 holds the
@@ -662,13 +674,15 @@ __global__ __launch_bounds__(kThreads, 2) void tdnn_pp_kernel(const TdnnArgs a) 
         pc.u = 0;
         pc.end = 0;
 
-        // tiles of this block: n units cut into ceil(n/4) tiles of 3 or 4 units, as equal as possible
-        // (n = 1, 2, 5 cannot be: the last tile then computes rows past the range and masks them)
+        // tiles of this block: n units cut into ceil(n/4) tiles of 4, 3 or 2 units, as equal as possible (5 = 3 + 2:
+        // without the 2-unit tile a batch of 128 utterances ran slower than one of 96); n = 1: one 2-unit tile whose
+        // second unit lies past the range and is masked
         const int n = (int)(u_end - u_begin);
         if (n <= 0) return;
         int nt = (n + 3) / 4;
         int base = n / nt, extra = n % nt;
-        if (base < 3) { base = 3; extra = 0; nt = (n + 2) / 3; }
+        constexpr int kMinMr = 2;
+        if (base < kMinMr) { base = kMinMr; extra = 0; nt = (n + kMinMr - 1) / kMinMr; }
         const int64_t range_end = u_end * 64;
 
         auto tile_at = [&](int idx, int64_t m0) {
@@ -681,16 +695,19 @@ __global__ __launch_bounds__(kThreads, 2) void tdnn_pp_kernel(const TdnnArgs a) 
         Tile cur = tile_at(0, u_begin * 64);
         if (POOL) pc = pool_cursor(a, cur.m0 + ln.grp * 32 * cur.mr);
         set_rows(a, cur, ln.grp, st, st.cur);
-        issue_head1(a, st, cur.mr);
-        issue_head2(a, st, cur.mr);
+        __syncthreads();                                   // constants visible; nobody reads LDS buffers yet
+        issue_head1<POOL>(a, st, cur.mr);
+        issue_head2<POOL>(a, st, cur.mr);
         for (int idx = 0; idx < nt; ++idx) {
             const bool has_next = idx + 1 < nt;
             Tile nxt = cur;
             if (has_next) nxt = tile_at(idx + 1, cur.m0 + 64 * cur.mr);
             if (cur.mr == 4)
-                process_tile<4, POOL>(a, smem, st, ln, cur, nxt, has_next, idx == 0, n0, nk, pc, cs);
+                process_tile<4, POOL>(a, smem, st, ln, cur, nxt, has_next, idx == 0, n0, nk, pc);
+            else if (cur.mr == 3)
+                process_tile<3, POOL>(a, smem, st, ln, cur, nxt, has_next, idx == 0, n0, nk, pc);
             else
-                process_tile<3, POOL>(a, smem, st, ln, cur, nxt, has_next, idx == 0, n0, nk, pc, cs);
+                process_tile<2, POOL>(a, smem, st, ln, cur, nxt, has_next, idx == 0, n0, nk, pc);
             cur = nxt;
         }
 #ifdef XVEC_DIAG

@@ -235,14 +235,14 @@ int run_tdnn(xvec_handle* h, int layer, TdnnVariant v, const void* X, int ldx, i
         a.x_bytes = x_rows > 0 ? x_plane + x_rows * (int64_t)ldx * 2 : 0;
     }
     StageTimer t(h, T_L1 + layer, s);
-    // bf16, wide layers, enough rows to give every CU at least three 64-frame units: the 256-channel
+    // bf16, wide layers, enough rows to give every CU a little over two 64-frame units: the 256-channel
     // ping-pong mapping (tdnn_pp.hip); everything else (small batches, layer 1, narrow models, fp32,
     // bf16x3) runs the 128x128 kernel
     if (h->use_pp && !x3 && layer > 0 && (v == TdnnVariant::kBf16 || v == TdnnVariant::kBf16Pool) && g.n_pad % 256 == 0) {
         const int n_cols = g.n_pad / 256;
         const int bpc = h->num_cu / n_cols;
         const int64_t units = (rows_out + 63) / 64;
-        if (bpc >= 1 && units >= 3 * (int64_t)bpc) {
+        if (bpc >= 1 && 5 * units >= 11 * (int64_t)bpc) {          // >= 2.2 units per CU (measured crossover, T = 300: 62 utterances)
             a.W = h->Wr16[layer];
             a.n_tiles = n_cols;
             a.blocks_per_col = bpc;

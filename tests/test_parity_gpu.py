@@ -479,3 +479,25 @@ def test_bf16x3_layers_and_full_size(gpu_model, sd42, synth):
                                C.c_void_p(ws.data_ptr()), C.c_size_t(n), None)
     assert rc == 1 and "bf16x3" in _hip.last_error()
 
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,T", [(63, 300), (100, 300), (128, 300), (160, 300), (70, 517)])
+def test_bf16_mid_size_batches(sd42, synth, gpu_model, B, T):
+    """Mid-size bf16 batches run the large-batch kernels with few units of 64 frames per CU: blocks of 2, 3 and 5
+    units (tiles of 2, 3, 3 + 2 rows of accumulators), partial last units.  Against the fp32 path of the same
+    library (bar 1e-2) and, row for row, against the same utterances in a batch of five (the 128x128 kernel)."""
+    import xvector_amd as xa
+    m = xa.XVectorModel(precision="bf16")
+    m.load_state_dict(sd42)
+    m = m.to(DEV)
+    x = _gpu(synth.make_mfcc(B, T, seed=B + T))
+    out = m.extract_x_vec(x)
+    assert torch.isfinite(out).all()
+    assert_parity(out, gpu_model.extract_x_vec(x), 1e-2, f"bf16 B={B} T={T} vs fp32", elem_tol=2e-2)
+    assert torch.equal(out, m.extract_x_vec(x))                                   # deterministic
+    idx = [0, 1, B // 2, B - 2, B - 1]
+    assert_parity(out[idx], m.extract_x_vec(x[idx]), 2e-4, "rows vs the small-batch kernel")
+    lens = np.random.default_rng(B).integers(T // 2, T + 1, B)
+    outr = m.extract_x_vec(x, lengths=lens.tolist())
+    assert_parity(outr, gpu_model.extract_x_vec(x, lengths=lens.tolist()), 1e-2, "ragged vs fp32", elem_tol=2e-2)

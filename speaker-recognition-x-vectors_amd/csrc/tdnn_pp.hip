@@ -23,7 +23,7 @@
 //     tiles would idle a quarter of the chip at B=256: 584 tiles over 256 CUs).
 //   * epilogues: frames in the accumulator's registers, the channel on the lane, and a lane's two accumulators
 //     hold ADJACENT channels (a row permutation of the packed weights, pack.hip); bias / scale / shift of those
-//     two channels stay in registers.  Store variant: ReLU + folded BatchNorm, v_cvt_pk_bf16_f32 joins the two
+//     two channels are 8-byte reads from a 3-KiB LDS table.  Store variant: ReLU + folded BatchNorm, v_cvt_pk_bf16_f32 joins the two
 //     columns and a store instruction writes two whole 128-byte row segments.  Pooling variant (layer 5): raw
 //     sums (sum r, sum r^2) of r = relu(z + bias) per (32-frame group, utterance), one 8-byte pair per lane.
 // The next tile's first K-tiles are requested before the epilogue, so the DMA flies under it.

@@ -14,12 +14,12 @@
 //     a DMA piece is lane-linear).  Two 64-KiB LDS buffers (K-tile parity), refilled slot by slot
 //     two K-tiles ahead behind COUNTED s_waitcnt vmcnt -- the queue is never drained in the loop.
 //   * 8 waves = 2 groups (frames halves) x 4 (64-channel columns); wave tile = MR x 2 accumulators
-//     of 32x32 (MR = 3 or 4 per tile: 192 or 256 frames).  The two waves of a SIMD belong to
+//     of 32x32 (MR = 2, 3 or 4 per tile: 128, 192 or 256 frames).  The two waves of a SIMD belong to
 //     different groups and run one barrier apart ("ping-pong"): while one issues its 16 MFMAs of a
 //     phase, the other reads its next fragments from LDS and issues its DMA pieces, then they swap.
 //     A phase = 2 accumulator rows x 2 columns x 4 k-steps; 2 phases per K-tile.
 //   * persistent: a block owns a contiguous range of 64-frame units of one 256-channel column and
-//     cuts it into tiles of 3 or 4 units, as equal as possible (a partial round of fixed 256-row
+//     cuts it into tiles of 4, 3 or 2 units, as equal as possible (a partial round of fixed 256-row
 //     tiles would idle a quarter of the chip at B=256: 584 tiles over 256 CUs).
 //   * epilogues: frames in the accumulator's registers, the channel on the lane, and a lane's two accumulators
 //     hold ADJACENT channels (a row permutation of the packed weights, pack.hip); bias / scale / shift of those

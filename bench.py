@@ -1,7 +1,12 @@
 #!/usr/bin/env python3
 """Headline benchmark: x-vector embeddings/s on 300-frame x 24-MFCC utterances.
 
-    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N>1 runs one rank per GPU over RCCL.  Either the caller starts the ranks (`python -m torch.distributed.run
+--nproc-per-node N ... bench.py --gpus N ...`: WORLD_SIZE is set) or bench.py does it itself: a plain
+`python bench.py --gpus N` starts that same launcher as a CHILD process before anything here touches the GPU,
+passes rank 0's JSON line through and exits with the child's code.
 
 One "step" = one pass of the extraction path (XVectorModel.extract_x_vec, layer 6) over one
 batch of 256 synthetic utterances already resident in HBM (BASELINE.json configs[1]).
@@ -56,6 +61,78 @@ def total_flops(T):
     return sum(layer_flops(T)) + 2 * 3000 * 512
 
 
+def self_launch(n, argv, port=0):
+    """`python bench.py --gpus N` without a launcher: start the N ranks with torch.distributed.run as a CHILD of
+    this process (which has made no HIP call: a process that has initialised the GPU must never exec or be
+    replaced), pass the child's stdout -- rank 0's single JSON line -- through and return its exit code."""
+    import socket
+    import subprocess
+    if not port:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL across processes needs it on this driver
+    # stdout carries exactly the ranks' JSON line(s); anything else a rank or a backend prints there (gloo's
+    # connection notes in a dry run) goes to stderr
+    with subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1) as child:
+        for line in child.stdout:
+            (sys.stdout if line.lstrip().startswith("{") else sys.stderr).write(line)
+            sys.stdout.flush()
+        return child.wait()
+
+
+def dry_run(args, world, rank):
+    """The N>1 control flow on CPU (gloo): barriers, K steps, the all-gather of [K*B,512] per rank (or the sharded
+    job), max-over-ranks timing, one JSON line from rank 0.  No GPU, no library, no measurement."""
+    import torch.distributed as dist
+    from xvector_amd import extract                     # host-side sharding logic only (no library, no device)
+    B, K = args.batch, args.steps
+    collective = world > 1 or args.force_collective
+    if collective:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        dist.init_process_group("gloo")
+    fake = lambda x: torch.full((x.shape[0], 512), float(rank))      # noqa: E731
+    if collective:
+        dist.barrier()
+    t0 = time.perf_counter()
+    if args.workload == "job":
+        full = extract.extract_sharded(fake, lambda lo, hi: torch.zeros((hi - lo, 1, 1)), args.utterances,
+                                       batch_size=B, force_collective=args.force_collective)
+        assert full.shape == (args.utterances, 512)
+        n_done = args.utterances
+    else:
+        emb = torch.cat([fake(torch.zeros((B, 1, 1))) for _ in range(K)])
+        if collective:
+            gathered = torch.empty((world * K * B, 512))
+            dist.all_gather_into_tensor(gathered, emb)
+            assert all(float(gathered[r * K * B, 0]) == r for r in range(world))
+        n_done = world * K * B
+    if collective:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if collective:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "x-vector embeddings/sec (300-frame utt)", "value": round(n_done / dt, 1), "unit": "embeddings/s",
+            "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": round(dt / max(K, 1) * 1e3, 4),
+            "higher_is_better": True, "scaling": "strong" if args.workload == "job" else "weak", "vs_baseline": None,
+            "dtype": "none", "data": "dry-run",
+            "config": {"workload": f"DRY RUN of the launch / collective path on CPU (gloo), {args.workload}; no GPU work",
+                       "batch_per_gpu": B, "sharding": f"utterance-sharded x{world}"}}), flush=True)
+    if collective:
+        dist.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -85,15 +162,22 @@ def main():
                          "one all-gather at the end (--steps is derived).  wave: 3 s waveforms at 16 kHz in HBM -> "
                          "MFCC front end (next row N3) -> the path (299 frames), one step = one batch")
     ap.add_argument("--utterances", type=int, default=100_000, help="job size of --workload job")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="rehearse the launch / collective / reporting path WITHOUT a GPU (CPU tests of the N>1 path): "
+                         "gloo backend, the extraction step replaced by a constant [B,512] tensor, no kernel figures; "
+                         "the line says data: \"dry-run\" and its value means nothing")
+    ap.add_argument("--master-port", type=int, default=0, help="rendezvous port of the self-launched ranks (0: pick a free one)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus, sys.argv[1:], args.master_port))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with python -m torch.distributed.run --nproc-per-node N")
         args.gpus = world
+    if args.dry_run:
+        return dry_run(args, world, rank)
 
     import torch.distributed as dist
     import xvector_amd as xa
@@ -344,9 +428,11 @@ def main():
         bf = args.dtype in ("bf16", "bf16x3")
         # bf16x3 spends three bf16 MFMAs per algorithmic product: its roof is a third of the bf16 peak
         peak = {"fp32": FP32_MFMA_PEAK, "bf16": BF16_MFMA_PEAK, "bf16x3": BF16_MFMA_PEAK / 3}[args.dtype]
-        # bf16 at this batch size runs the 256-channel ping-pong mapping (csrc/tdnn_pp.hip); smaller batches and
-        # bf16x3 the 128x128 kernel (csrc/tdnn_layer.hip)
-        pp16 = args.dtype == "bf16" and 5 * -(-B * (T - 14) // 64) >= 11 * 128      # run_tdnn's dispatch rule
+        # which kernel layers 2-4 actually went to, as the library reports it (xvec_get_dispatch): bf16 at this batch
+        # size runs the 256-channel ping-pong mapping (csrc/tdnn_pp.hip); smaller batches, other CU counts, XVEC_PP=0
+        # and bf16x3 the 128x128 kernel (csrc/tdnn_layer.hip)
+        disp = model.last_dispatch(dev)
+        pp16 = disp[1:4] == ["pp", "pp", "pp"]
         dom_kernel = ("xvec::pp::tdnn_pp_kernel<false> (layers 2-4, bf16 MFMA, LDS-DMA operands)" if pp16 else
                       "xvec::tdnn_kernel<0,false,true,true,true,X3> (layers 2-4, bf16 MFMA"
                       + (", three products per k-step)" if args.dtype == "bf16x3" else ")") if bf else
@@ -405,15 +491,18 @@ def main():
             import xvector_oracle as oracle
             p = {k: v for k, v in sd.items() if v.is_floating_point()}
             legs = oracle.time_cpu_baseline(p, T=T, budget_s=args.cpu_budget, threads=usable_cpus())
-            head = legs["b64_all"]
+            best = max(legs, key=lambda k: legs[k]["embeddings_per_s"])      # the fastest honest CPU leg is the headline
+            head = legs[best]
             secs = sum(l["seconds"] for l in legs.values())
             out["cpu_baseline"] = {
                 "value": head["embeddings_per_s"], "unit": "embeddings/s", "cores": head["threads"], "kind": "port",
+                "leg": best,
                 "sample": f"{T}-frame utterances, fp32, oracle/xvector_oracle.py (PyTorch CPU restatement of the "
                           f"reference's op sequence), SURVEY 8(d) protocol: B=64 and B=1, {head['threads']} threads and 1 "
                           f"thread, 3 warm-ups + median of 10 per leg (a leg that would not fit its share of the "
                           f"{args.cpu_budget:.0f} s budget is cut to 1 warm-up + >=3 timed passes: see legs.*.reps); "
-                          f"value = B=64 on all {head['threads']} usable cores; {secs:.1f} s of CPU work in all",
+                          f"value = the fastest of the four legs ({best}: B={head.get('batch', '?')}, {head['threads']} "
+                          f"thread(s)); {secs:.1f} s of CPU work in all",
                 "legs": legs}
         print(json.dumps(out), flush=True)
     if collective:

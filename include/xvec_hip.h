@@ -11,7 +11,7 @@
  *   - tensors are contiguous, batch-first, time-major, channels-last, fp32 -- exactly the
  *     [B,T,C] layout the reference feeds (main.py:99,137);
  *   - all work is enqueued on the caller's stream and is asynchronous w.r.t. the host; nothing
- *     allocates device or pinned memory after xvec_create (the fixed-length path is therefore
+ *     allocates device, pinned or host heap memory after xvec_create (the fixed-length path is therefore
  *     capturable into a hipGraph).  What is synchronous: xvec_create / xvec_destroy; xvec_get_timings
  *     (waits for the last recorded event); and the ragged entry points (lengths_host / offsets_host
  *     given) copy the offsets through a ring of two pinned staging slots owned by the handle, so
@@ -19,7 +19,7 @@
  *   - every entry point that takes a handle runs on the handle's device and leaves the calling
  *     thread's current device as it found it (xvec_create included);
  *   - limits: at most 65535 utterances per call; input_size, hidden_size <= 8192; rows are addressed
- *     with 32-bit byte offsets, so (utterances x context + 136) x channels x element size must stay
+ *     with 32-bit byte offsets, so (utterances x context + 264) x channels x element size must stay
  *     below 2^31 (XVEC_ERR_ARG otherwise -- split the batch);
  *   - every function returns XVEC_OK (0) or an error code and never throws; the message
  *     for the last error on the calling thread is available from xvec_last_error();
@@ -54,6 +54,8 @@ enum {
 /* what xvec_forward returns */
 enum {
     XVEC_MODE_LOGITS = 0, /* XVectorModel.forward        main.py:66-75  -> [B,num_classes] */
+    XVEC_MODE_POOLED = 5, /* stat_pool(time_context_layers(x)), main.py:68-69 / 83-84 -> [B,3000] = mean | std:
+                           * the frame-level stack with its fused pooling alone (segment-level weights not needed) */
     XVEC_MODE_XVEC6 = 6,  /* extract_x_vec, layer 6      main.py:86-87  -> [B,x_vector_size] */
     XVEC_MODE_XVEC7 = 7   /* extract_x_vec, layer 7      main.py:88-90  -> [B,x_vector_size] */
 };
@@ -108,7 +110,7 @@ size_t xvec_workspace_bytes(const xvec_handle* h, int64_t total_frames, int32_t 
  *                 un-padded slice alone (BASELINE config 3).
  *   mode:         XVEC_MODE_*;  dtype: XVEC_F32 / XVEC_BF16 / XVEC_BF16X3 (the last one: at most
  *                 ~1M frames per call at 512 channels -- its second plane is addressed with 30 bits)
- *   out:          [B, num_classes] (logits) or [B, x_vector_size]
+ *   out:          [B, num_classes] (logits), [B, x_vector_size] or [B, 2*XVEC_POOL_CHANNELS] (XVEC_MODE_POOLED)
  * Errors: T (or a length) < 15 -> XVEC_ERR_ARG (the reference silently yields empty
  * tensors / NaN there); weights not loaded -> XVEC_ERR_STATE. */
 int xvec_forward(xvec_handle* h, const float* x, const int32_t* lengths_host, int32_t B,
@@ -126,6 +128,11 @@ int xvec_forward_packed(xvec_handle* h, const float* x_packed, const int64_t* of
  * x[B,T,in] -> y[B,T-(c[-1]-c[0]),out].  workspace >= xvec_workspace_bytes(h, B*T, B). */
 int xvec_tdnn_layer(xvec_handle* h, int layer, const float* x, int32_t B, int32_t T, int dtype,
                     float* y, void* workspace, size_t workspace_bytes, xvec_stream stream);
+/* stat_pool(time_context_layers[4](x)) (main.py:44,59-63 as forward composes them, main.py:68-69): the last
+ * frame-level layer with the statistics pooling fused into its epilogue, exactly as xvec_forward runs it, on a
+ * caller-given input x[B,T,hidden] -> out[B, 2*XVEC_POOL_CHANNELS].  workspace >= xvec_workspace_bytes(h, B*T, B). */
+int xvec_tdnn_pool_layer(xvec_handle* h, const float* x, int32_t B, int32_t T, int dtype, float* out,
+                         void* workspace, size_t workspace_bytes, xvec_stream stream);
 /* XVectorModel.stat_pool (main.py:59-63): x[B,T,C] -> out[B,2C] = mean ‖ unbiased std.
  * lengths_dev: NULL or DEVICE int32[B] valid-frame counts (mask).  Stand-alone: no handle. */
 int xvec_stat_pool(const float* x, const int32_t* lengths_dev, int32_t B, int32_t T, int32_t C,
@@ -145,6 +152,15 @@ int xvec_affine(xvec_handle* h, int which, const float* x, int32_t M, int relu, 
  * covers both launches of its split-K form; *n = 10. */
 int xvec_set_profiling(xvec_handle* h, int on);
 int xvec_get_timings(xvec_handle* h, float* ms, int* n);
+/* Which kernel the LAST launch of each frame-level layer went to (the choice depends on arithmetic, widths and
+ * batch size): kernels[0..4], *n = 5.  bench.py names its roofline kernel and keys profiles/traffic.json by this. */
+enum {
+    XVEC_KERNEL_NONE = 0,
+    XVEC_KERNEL_TILE128 = 1, /* xvec::tdnn_kernel<...>          128x128 tiles (csrc/tdnn_layer.hip) */
+    XVEC_KERNEL_PP = 2,      /* xvec::pp::tdnn_pp_kernel<POOL>  256-channel LDS-DMA mapping, bf16 at large batches (csrc/tdnn_pp.hip) */
+    XVEC_KERNEL_FIRST = 3    /* xvec::first::tdnn_first_kernel  layer 1 of the bf16 path, streaming (csrc/tdnn_first.hip) */
+};
+int xvec_get_dispatch(const xvec_handle* h, int* kernels, int* n);
 
 /* ---- next row N3: MFCC front end (the step in front of the path) ----------------------------
  * python_speech_features.mfcc as the reference calls it in its DataLoader workers

@@ -4,7 +4,7 @@
 A=$1; B=$2; shift 2
 for i in 1 2 3; do
   for L in "$A" "$B"; do
-    XVEC_LIB=$L python bench.py --steps 30 --warmup 5 --cpu-budget 0 "$@" 2>/dev/null | python -c "
+    XVEC_LIB=$(realpath $L) python bench.py --steps 30 --warmup 5 --cpu-budget 0 "$@" 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.readline())
 k = d['roofline']['per_kernel_ms']

@@ -1,6 +1,6 @@
 """Core clock inside the bf16 path under sustained load (diagnostic build): block 0 of the last layer-4 launch and of
 the layer-5 launch record s_memtime (core cycles) and s_memrealtime (100 MHz) at entry and exit.
-usage: XVEC_LIB=profiles/diag/bin/libxvec_hip_diag.so python profiles/diag/pp_clock.py [iterations]"""
+usage: XVEC_LIB=$PWD/build/diag/libxvec_hip_diag.so python profiles/diag/pp_clock.py [iterations]"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch

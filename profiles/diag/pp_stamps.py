@@ -1,5 +1,5 @@
 """Segment anatomy of tdnn_pp_kernel (diagnostic build, s_memtime stamps of waves 0 and 4 of every block).
-usage: XVEC_LIB=profiles/diag/bin/libxvec_hip_diag.so python profiles/diag/pp_stamps.py [layer ...]"""
+usage: XVEC_LIB=$PWD/build/diag/libxvec_hip_diag.so python profiles/diag/pp_stamps.py [layer ...]"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch

@@ -4,7 +4,7 @@
 //  * stat_pool_kernel     -- stand-alone, HBM-bound: one pass over x with the first frame of
 //                            the utterance as a shift (sums of (x-K), (x-K)^2 are well
 //                            conditioned since K is a sample of the same distribution).
-//  * pool_finalize_kernel -- adds up the per-sub-tile raw-sum partials that the layer-5
+//  * pool_finalize_kernel -- merges the per-sub-tile pivoted partials that the layer-5
 //                            epilogues (tdnn_layer.hip, tdnn_pp.hip) write, in fp64.
 //
 // n == 1 gives NaN std exactly like torch.std (0/0); the caller rejects n < 1.
@@ -107,44 +107,57 @@ hipError_t launch_stat_pool(const PoolArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-// One thread per (utterance, channel): add up the raw-sum partials (S1, S2) = sums of r and r^2,
-// r = relu(z + bias), that the layer-5 epilogues (tdnn_layer.hip, tdnn_pp.hip) wrote per (32-row sub-tile,
-// utterance), then apply the folded BatchNorm y = scale*r + shift:
-//   mean = shift + scale*S1/n,   std = |scale| * sqrt((S2 - S1^2/n) / (n-1)),
-// totals and the difference in fp64.  Four sub-tiles per trip, their eight loads issued before the first add:
-// the kernel is a chain of ~10 dependent round trips per thread otherwise.
+// One thread per (utterance, channel): merge the partials (K, S1, S2) -- pivot, sum (r - K), sum (r - K)^2 over the
+// utterance's n_g frames in the sub-tile, r = relu(z + bias) -- that the layer-5 epilogues (tdnn_layer.hip,
+// tdnn_pp.hip) wrote per (32-row sub-tile, utterance), then apply the folded BatchNorm y = scale*r + shift.
+// Every sub-tile's sums are re-based to the pivot K0 of the utterance's first sub-tile in fp64
+// (d = K - K0:  S1' = S1 + n_g*d,  S2' = S2 + 2*d*S1 + n_g*d^2: multiply-adds only), so
+//   mean = shift + scale*(K0 + S1'/n),   std = |scale| * sqrt((S2' - S1'^2/n) / (n-1))
+// cancel in fp64 about a sample of the channel; the fp32 sums inside a partial are sums of deviations
+// (tdnn_common.h, pool_group_impl).  torch.std (main.py:61) is two-pass: this matches it to fp32 rounding of
+// the inputs also for |mean| >> std.  Four sub-tiles per trip, their loads issued before the first add: the kernel
+// is a chain of ~10 dependent round trips per thread otherwise.
 __global__ __launch_bounds__(256) void pool_finalize_kernel(const PoolFinalizeArgs a) {
     const int u = blockIdx.y;
     const int ch = blockIdx.x * 256 + threadIdx.x;
     if (ch >= a.C) return;
     const int64_t off = row_off(a.map, u), end = row_off(a.map, u + 1);   // pooled rows are [off, end)
-    double s1 = 0.0, s2 = 0.0;
-    const int64_t sub_end = (end + a.sub_rows - 1) / a.sub_rows;          // sub-tiles [off / sub_rows, sub_end)
-    for (int64_t sub0 = off / a.sub_rows; sub0 < sub_end; sub0 += 4) {
-        float p1[4], p2[4];
+    double s1 = 0.0, s2 = 0.0, k0 = 0.0;
+    const int64_t sub_first = off / a.sub_rows;
+    const int64_t sub_end = (end + a.sub_rows - 1) / a.sub_rows;          // sub-tiles [sub_first, sub_end)
+    for (int64_t sub0 = sub_first; sub0 < sub_end; sub0 += 4) {
+        float pk[4], p1[4], p2[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
+            pk[j] = 0.f;
             p1[j] = 0.f;
             p2[j] = 0.f;
             if (sub0 + j < sub_end) {
-                const float* p = a.part + (sub0 + j + u) * (int64_t)(2 * a.n_pad);
-                p1[j] = p[ch];
-                p2[j] = p[a.n_pad + ch];
+                const float* p = a.part + (sub0 + j + u) * (int64_t)(3 * a.n_pad);
+                pk[j] = p[ch];
+                p1[j] = p[a.n_pad + ch];
+                p2[j] = p[2 * a.n_pad + ch];
             }
         }
+        if (sub0 == sub_first) k0 = (double)pk[0];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            s1 += (double)p1[j];
-            s2 += (double)p2[j];
+            if (sub0 + j < sub_end) {
+                const int64_t lo = (sub0 + j) * a.sub_rows > off ? (sub0 + j) * a.sub_rows : off;
+                const int64_t hi = (sub0 + j + 1) * a.sub_rows < end ? (sub0 + j + 1) * a.sub_rows : end;
+                const double ng = (double)(hi - lo), d = (double)pk[j] - k0, t1 = (double)p1[j];
+                s1 += t1 + ng * d;
+                s2 += (double)p2[j] + d * (2.0 * t1 + ng * d);
+            }
         }
     }
     const double n = (double)(end - off);
     const double sc = (double)a.scale[ch], sh = (double)a.shift[ch];
-    const double mean_r = s1 / n;
-    double var_r = (s2 - s1 * mean_r) / (n - 1.0);
+    const double mean_d = s1 / n;                       // mean of (r - K0)
+    double var_r = (s2 - s1 * mean_d) / (n - 1.0);
     var_r = var_r > 0.0 ? var_r : 0.0;
     float* o = a.out + (int64_t)u * 2 * a.C;
-    o[ch] = (float)(sh + sc * mean_r);
+    o[ch] = (float)(sh + sc * (k0 + mean_d));
     // n == 1 gives NaN like torch.std (0/0)
     o[a.C + ch] = (n > 1.0) ? (float)((sc < 0.0 ? -sc : sc) * sqrt(var_r)) : __builtin_nanf("");
 }

@@ -43,7 +43,7 @@ __device__ __forceinline__ u32x4 cvt8(const u32x4& lo, const u32x4& hi) {
 
 // staged input of one thread: k-step `ks` (16 values) of frame `rr` of the group
 struct Staged {
-    u32x4 q0, q1, q2, q3;                  // SRC32: 16 floats; else q0, q1 = 16 bf16
+    u32x4 q0, q1, q2, q3;                  // 16 floats of the caller's fp32 rows
 };
 
 template <bool RAGGED>
@@ -59,7 +59,7 @@ struct Cur {
     int64_t end;
 };
 
-template <bool SRC32, bool RAGGED>
+template <bool RAGGED>
 __device__ __forceinline__ void fetch(const TdnnArgs& a, int64_t g, Cur& cu, int rr, int ks, Staged& st) {
     const RowMap& m = a.out_map;
     const int64_t m0 = g * 32;
@@ -79,7 +79,7 @@ __device__ __forceinline__ void fetch(const TdnnArgs& a, int64_t g, Cur& cu, int
             nxt = first_row_of<RAGGED>(m, u + 1);
         }
     }
-    constexpr int ES = SRC32 ? 4 : 2;
+    constexpr int ES = 4;                  // the input rows are the caller's fp32 MFCCs, rounded to bf16 in park()
     // descriptor at the group's first input row (64-bit), bounded by the end of the caller's tensor: reads past
     // it return zeros; the lane offset is small (a group's rows + the utterances it skips)
     const int64_t row0 = m0 + (int64_t)cu.u * a.span;
@@ -88,24 +88,14 @@ __device__ __forceinline__ void fetch(const TdnnArgs& a, int64_t g, Cur& cu, int
     const int voff = ((rr + c * a.span) * a.ldx + 16 * ks) * ES;
     st.q0 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, voff, 0, 0));
     st.q1 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, voff, 16, 0));
-    if (SRC32) {
-        st.q2 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, voff, 32, 0));
-        st.q3 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, voff, 48, 0));
-    }
+    st.q2 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, voff, 32, 0));
+    st.q3 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, voff, 48, 0));
 }
 
-// round (SRC32), blank the K tail (values past kpt belong to the next frame and meet zero weights, but
+// round to bf16, blank the K tail (values past kpt belong to the next frame and meet zero weights, but
 // 0 x Inf is not 0) and park the 32 bytes in the LDS tile
-template <bool SRC32>
 __device__ __forceinline__ void park(const TdnnArgs& a, char* tile, int rr, int ks, const Staged& st) {
-    u32x4 lo, hi;
-    if (SRC32) {
-        lo = cvt8(st.q0, st.q1);
-        hi = cvt8(st.q2, st.q3);
-    } else {
-        lo = st.q0;
-        hi = st.q1;
-    }
+    u32x4 lo = cvt8(st.q0, st.q1), hi = cvt8(st.q2, st.q3);
     const int k0 = 16 * ks;
     if (k0 + 16 > a.kpt) {                 // only the last k-step(s) of a row: pairs of bf16 per dword
 #pragma unroll
@@ -119,7 +109,7 @@ __device__ __forceinline__ void park(const TdnnArgs& a, char* tile, int rr, int 
     *reinterpret_cast<u32x4*>(tile + rr * kRowB + ks * 32 + 16) = hi;
 }
 
-template <bool SRC32, bool RAGGED>
+template <bool RAGGED>
 __global__ __launch_bounds__(256, 2) void tdnn_first_kernel(const TdnnArgs a) {
     __shared__ __attribute__((aligned(16))) char smem[2 * kTileB + kConstFloats * 4];
     float* cst = reinterpret_cast<float*>(smem + 2 * kTileB);
@@ -159,9 +149,9 @@ __global__ __launch_bounds__(256, 2) void tdnn_first_kernel(const TdnnArgs a) {
     // full write rate: 6 us per group, no faster than the 128x128 kernel).  The loads of group g+2 are issued
     // before the stores of group g, and the wait for group g+1's loads leaves the newer operations in flight.
     Staged sa, sb;
-    fetch<SRC32, RAGGED>(a, g_begin, cu, rr, sks, sa);
-    park<SRC32>(a, smem, rr, sks, sa);
-    if (g_begin + 1 < g_end) fetch<SRC32, RAGGED>(a, g_begin + 1, cu, rr, sks, sb);
+    fetch<RAGGED>(a, g_begin, cu, rr, sks, sa);
+    park(a, smem, rr, sks, sa);
+    if (g_begin + 1 < g_end) fetch<RAGGED>(a, g_begin + 1, cu, rr, sks, sb);
     __syncthreads();                               // constants + tile 0 visible
 
     const char* frag = smem + r * kRowB + 16 * h;  // A operand of lane (r, h): frame r, k = 16*ks + 8*h ..+7
@@ -183,7 +173,7 @@ __global__ __launch_bounds__(256, 2) void tdnn_first_kernel(const TdnnArgs a) {
     // g+2 into the set that was parked last time (ST_FETCH), epilogue + stores
 #define XF_GROUP(g_, buf_, ST_PARK, ST_FETCH)                                                                     \
     {                                                                                                             \
-        if ((g_) + 2 < g_end) fetch<SRC32, RAGGED>(a, (g_) + 2, cu, rr, sks, ST_FETCH);                           \
+        if ((g_) + 2 < g_end) fetch<RAGGED>(a, (g_) + 2, cu, rr, sks, ST_FETCH);                           \
         f32x16 acc[4];                                                                                            \
         _Pragma("unroll") for (int cg = 0; cg < 4; ++cg)                                                          \
             _Pragma("unroll") for (int e = 0; e < 16; ++e) acc[cg][e] = 0.f;                                      \
@@ -194,7 +184,7 @@ __global__ __launch_bounds__(256, 2) void tdnn_first_kernel(const TdnnArgs a) {
                 acc[cg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, xf),                 \
                                                                   __builtin_bit_cast(bf16x8, wf[cg][ks]), acc[cg], 0, 0, 0); \
         }                                                                                                         \
-        if ((g_) + 1 < g_end) park<SRC32>(a, smem + ((buf_) ^ 1) * kTileB, rr, sks, ST_PARK);                     \
+        if ((g_) + 1 < g_end) park(a, smem + ((buf_) ^ 1) * kTileB, rr, sks, ST_PARK);                     \
         /* bias + ReLU + folded BatchNorm (tdnn_layer.py:30-39); rows of the group at g*32 (the row buffer is */  \
         /* padded past the last valid frame) */                                                                   \
         const __amdgpu_buffer_rsrc_t yr = make_rsrc(static_cast<char*>(a.Y) + (g_) * 32 * (int64_t)a.ldy * 2);    \
@@ -218,22 +208,16 @@ __global__ __launch_bounds__(256, 2) void tdnn_first_kernel(const TdnnArgs a) {
 
 }  // namespace first
 
-bool tdnn_first_applicable(const TdnnArgs& a, int es) {
-    return a.ldy == 512 && a.k_pad == 128 && a.n_taps == 1 && a.kpt <= 128 && a.terms == 1 && (a.ldx * es) % 16 == 0 &&
+bool tdnn_first_applicable(const TdnnArgs& a) {
+    return a.ldy == 512 && a.k_pad == 128 && a.n_taps == 1 && a.kpt <= 128 && a.terms == 1 && (a.ldx * 4) % 16 == 0 &&
            (reinterpret_cast<uintptr_t>(a.X) & 15) == 0 && a.groups_total > 0;
 }
 
-hipError_t launch_tdnn_first(const TdnnArgs& a, bool src32, int num_cu, hipStream_t s) {
+hipError_t launch_tdnn_first(const TdnnArgs& a, int num_cu, hipStream_t s) {
     const int64_t want = 2 * (int64_t)num_cu;      // one block per CU measured 30 us against 28
     const int grid = (int)(a.groups_total < want ? a.groups_total : want);
-    const bool ragged = a.out_map.offsets != nullptr;
-    if (src32) {
-        if (ragged) first::tdnn_first_kernel<true, true><<<grid, 256, 0, s>>>(a);
-        else first::tdnn_first_kernel<true, false><<<grid, 256, 0, s>>>(a);
-    } else {
-        if (ragged) first::tdnn_first_kernel<false, true><<<grid, 256, 0, s>>>(a);
-        else first::tdnn_first_kernel<false, false><<<grid, 256, 0, s>>>(a);
-    }
+    if (a.out_map.offsets != nullptr) first::tdnn_first_kernel<true><<<grid, 256, 0, s>>>(a);
+    else first::tdnn_first_kernel<false><<<grid, 256, 0, s>>>(a);
     return hipGetLastError();
 }
 

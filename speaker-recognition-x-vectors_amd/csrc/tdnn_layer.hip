@@ -36,10 +36,10 @@
 //     pipe for ~450 cycles each; spread out they are free.
 //
 // Epilogue: bias + ReLU + folded BatchNorm in registers; optional fused statistics pooling
-// (main.py:59-63): per 32-row group and per utterance overlapping it, the column mean and
-// M2 (sum of squared deviations about that mean) of the valid frames go to a small partials
-// buffer that pool_finalize merges (Chan et al.), so the [frames,1500] activation of layer 5
-// never goes to HBM.
+// (main.py:59-63): per 32-row group and per utterance overlapping it, a pivot K (the group's frame 0)
+// and the sums of (r - K), (r - K)^2 over the valid frames, r = relu(z + bias), go to a small partials
+// buffer that pool_finalize merges in fp64 (tdnn_common.h, pool_group_impl), so the [frames,1500]
+// activation of layer 5 never goes to HBM.
 #include <cstdlib>
 
 #include "tdnn_common.h"

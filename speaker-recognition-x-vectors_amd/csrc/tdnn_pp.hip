@@ -24,8 +24,8 @@
 //   * epilogues: frames in the accumulator's registers, the channel on the lane, and a lane's two accumulators
 //     hold ADJACENT channels (a row permutation of the packed weights, pack.hip); bias / scale / shift of those
 //     two channels are 8-byte reads from a 3-KiB LDS table.  Store variant: ReLU + folded BatchNorm, v_cvt_pk_bf16_f32 joins the two
-//     columns and a store instruction writes two whole 128-byte row segments.  Pooling variant (layer 5): raw
-//     sums (sum r, sum r^2) of r = relu(z + bias) per (32-frame group, utterance), one 8-byte pair per lane.
+//     columns and a store instruction writes two whole 128-byte row segments.  Pooling variant (layer 5): pivoted
+//     sums (K, sum (r-K), sum (r-K)^2) of r = relu(z + bias) per (32-frame group, utterance), 8-byte pairs per lane.
 // The next tile's first K-tiles are requested before the epilogue, so the DMA flies under it.
 #include "tdnn_common.h"
 
@@ -399,11 +399,10 @@ struct Lane {
 // Fused statistics pooling for the pooling variant (main.py:59-63), frames in the accumulator registers and
 // the channel on the lane.  The epilogue runs in the open here (both waves of a SIMD are in it at the same
 // time, the matrix pipe idles), so it is as short as the arithmetic allows: per (32-frame group, utterance)
-// and channel the RAW sums S1 = sum r, S2 = sum r^2 of r = relu(z + bias) over the utterance's frames in the
-// group -- one v_max, one add and one fma per value.  Scale and shift of the folded BatchNorm are applied
-// by pool_finalize (mean = shift + scale*S1/n, std = |scale|*sqrt((S2 - S1^2/n)/(n-1)) with the totals and
-// the difference taken in fp64); r >= 0 keeps the cancellation in S2 - S1^2/n mild (relative error of the
-// variance ~1e-7*(1 + mean^2/var)), far inside this bf16 path's 1e-2 bar.
+// and channel the pivoted sums S1 = sum (r - K), S2 = sum (r - K)^2 of r = relu(z + bias) over the utterance's
+// frames in the group, K = the group's frame 0 (tdnn_common.h, pool_group_impl: why a pivot) -- one v_max, half a
+// v_pk_add for the pivot, half a v_pk_add and half a v_pk_fma per value.  Scale and shift of the folded BatchNorm
+// are applied by pool_finalize.
 // v0 / v1: this wave's two accumulators for the group at compact row row_g -- the lane's channels col0 and
 // col0 + 1 (bias already inside: the accumulators start at it).
 // Returns true when the group lay inside one utterance.
@@ -428,21 +427,24 @@ __device__ __forceinline__ bool pool_raw_pair(const TdnnArgs& a, const f32x16& v
     const int64_t grp = row_g >> 5;
     const int ld = a.ldy;
     const __amdgpu_buffer_rsrc_t prs = make_rsrc(a.pool_part);
+    // pivots: the group's frame 0 of the lane's two channels (tdnn_common.h, pool_group_impl)
+    const float ka = lower_half(fmaxf(v0[0], 0.f)), kb = lower_half(fmaxf(v1[0], 0.f));
     if (pc.end >= row_g + 32) {               // the whole group belongs to utterance pc.u
         // two values per instruction where the ISA has one (v_pk_add_f32 / v_pk_fma_f32; the max has none)
+        const f32x2 kka = {ka, ka}, kkb = {kb, kb};
         f32x2 p1a = {0.f, 0.f}, p2a = {0.f, 0.f}, p1b = {0.f, 0.f}, p2b = {0.f, 0.f};
 #pragma unroll
         for (int e = 0; e < 16; e += 2) {
-            const f32x2 ra = {fmaxf(v0[e], 0.f), fmaxf(v0[e + 1], 0.f)};
-            const f32x2 rb = {fmaxf(v1[e], 0.f), fmaxf(v1[e + 1], 0.f)};
-            p1a += ra;
-            p2a = __builtin_elementwise_fma(ra, ra, p2a);
-            p1b += rb;
-            p2b = __builtin_elementwise_fma(rb, rb, p2b);
+            const f32x2 da = f32x2{fmaxf(v0[e], 0.f), fmaxf(v0[e + 1], 0.f)} - kka;
+            const f32x2 db = f32x2{fmaxf(v1[e], 0.f), fmaxf(v1[e + 1], 0.f)} - kkb;
+            p1a += da;
+            p2a = __builtin_elementwise_fma(da, da, p2a);
+            p1b += db;
+            p2b = __builtin_elementwise_fma(db, db, p2b);
         }
         const float s1a = add_halves(p1a.x + p1a.y), s2a = add_halves(p2a.x + p2a.y);
         const float s1b = add_halves(p1b.x + p1b.y), s2b = add_halves(p2b.x + p2b.y);
-        store_partial2(prs, ld, grp + pc.u, h, col0, s1a, s2a, s1b, s2b);
+        store_partial2(prs, ld, grp + pc.u, h, col0, ka, kb, s1a, s2a, s1b, s2b);
         return true;
     }
     for (int u = pc.u; u < m.n_utts; u = __builtin_amdgcn_readfirstlane(u + 1)) {   // the group straddles utterances
@@ -459,17 +461,17 @@ __device__ __forceinline__ bool pool_raw_pair(const TdnnArgs& a, const f32x16& v
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const bool in = (lm >> ((e & 3) + 8 * (e >> 2))) & 1u;      // a SELECT: rows outside may hold anything
-            const float ra = in ? fmaxf(v0[e], 0.f) : 0.f, rb = in ? fmaxf(v1[e], 0.f) : 0.f;
-            s1a += ra;
-            s2a = fmaf(ra, ra, s2a);
-            s1b += rb;
-            s2b = fmaf(rb, rb, s2b);
+            const float da = in ? fmaxf(v0[e], 0.f) - ka : 0.f, db = in ? fmaxf(v1[e], 0.f) - kb : 0.f;
+            s1a += da;
+            s2a = fmaf(da, da, s2a);
+            s1b += db;
+            s2b = fmaf(db, db, s2b);
         }
         s1a = add_halves(s1a);
         s2a = add_halves(s2a);
         s1b = add_halves(s1b);
         s2b = add_halves(s2b);
-        store_partial2(prs, ld, grp + u, h, col0, s1a, s2a, s1b, s2b);
+        store_partial2(prs, ld, grp + u, h, col0, ka, kb, s1a, s2a, s1b, s2b);
     }
     return false;
 }

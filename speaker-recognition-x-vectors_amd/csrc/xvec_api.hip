@@ -85,6 +85,7 @@ struct xvec_handle {
     int offs_next;
     int num_cu;
     int blocks_per_cu;                 // persistent TDNN blocks per CU (LDS allows 2)
+    int last_kernel[XVEC_NUM_TDNN];    // XVEC_KERNEL_* the last launch of each frame-level layer went to (xvec_get_dispatch)
     // profiling
     bool profiling;
     hipEvent_t ev0[T_COUNT], ev1[T_COUNT];
@@ -114,7 +115,7 @@ Plan make_plan(const xvec_handle* h, int64_t total, int B) {
     p.actB = o;   o += align_up((size_t)p.rows_alloc * nh * 4);
     p.act5 = o;   o += align_up((size_t)p.rows_alloc * (n5 > nh ? n5 : nh) * 4);   // also the fp32 output of xvec_tdnn_layer
     p.part_slots = p.m_pad / 32 + B + 1;
-    p.part = o;   o += align_up((size_t)p.part_slots * 2 * n5 * 4);   // (addressed with 32-bit offsets: forward_rows checks < 2 GiB)
+    p.part = o;   o += align_up((size_t)p.part_slots * 3 * n5 * 4);   // (addressed with 32-bit offsets: forward_rows checks < 2 GiB)
     p.pooled = o; o += align_up((size_t)B * 2 * XVEC_POOL_CHANNELS * 4);
     p.seg6 = o;   o += align_up((size_t)B * h->cfg.x_vector_size * 4);
     p.seg7 = o;   o += align_up((size_t)B * h->cfg.x_vector_size * 4);
@@ -218,7 +219,7 @@ int run_tdnn(xvec_handle* h, int layer, TdnnVariant v, const void* X, int ldx, i
     {
         // the kernel addresses its input with 32-bit byte offsets from a per-tile descriptor: the
         // largest is (rows of a tile + look-ahead + u*span re-basing) * row bytes (+ the lo plane)
-        const int64_t es = in16 ? 2 : 4;
+        const int64_t es = (in16 && v != TdnnVariant::kBf16FirstSrc32) ? 2 : 4;   // element size of the rows READ
         const int64_t reach = ((int64_t)out_map.n_utts * a.span + kRowPadTail) * ldx * es + (x3 ? x_plane : 0);
         if (reach > 0x7fffffff)
             return fail(XVEC_ERR_ARG, "layer %d: %d utterances x %d channels exceed 32-bit row offsets; split the batch",
@@ -249,23 +250,24 @@ int run_tdnn(xvec_handle* h, int layer, TdnnVariant v, const void* X, int ldx, i
             a.groups_total = units;
             a.pair_period = 0;
             HIP_TRY(launch_tdnn_pp(a, v == TdnnVariant::kBf16Pool, s));
+            h->last_kernel[layer] = XVEC_KERNEL_PP;
             return XVEC_OK;
         }
     }
-    if (h->use_pp && layer == 0 && (v == TdnnVariant::kBf16First || v == TdnnVariant::kBf16FirstSrc32)) {
-        const bool src32 = v == TdnnVariant::kBf16FirstSrc32;
-        if (tdnn_first_applicable(a, src32 ? 4 : 2)) {
-            HIP_TRY(launch_tdnn_first(a, src32, h->num_cu, s));
-            return XVEC_OK;
-        }
+    if (h->use_pp && layer == 0 && v == TdnnVariant::kBf16FirstSrc32 && tdnn_first_applicable(a)) {
+        HIP_TRY(launch_tdnn_first(a, h->num_cu, s));
+        h->last_kernel[layer] = XVEC_KERNEL_FIRST;
+        return XVEC_OK;
     }
     HIP_TRY(launch_tdnn(a, v, s));
+    h->last_kernel[layer] = XVEC_KERNEL_TILE128;
     return XVEC_OK;
 }
 
 int check_loaded(const xvec_handle* h, int mode) {
     for (int i = 0; i < XVEC_NUM_TDNN; ++i)
         if (!h->tdnn_loaded[i]) return fail(XVEC_ERR_STATE, "time_context_layers.%d weights not loaded", i);
+    if (mode == XVEC_MODE_POOLED) return XVEC_OK;
     if (!h->aff_loaded[0]) return fail(XVEC_ERR_STATE, "segment_layer6 weights not loaded");
     if ((mode == XVEC_MODE_XVEC7 || mode == XVEC_MODE_LOGITS) && !h->aff_loaded[1])
         return fail(XVEC_ERR_STATE, "segment_layer7 weights not loaded");
@@ -279,7 +281,7 @@ int forward_rows(xvec_handle* h, const float* x_rows, int ldx, const int64_t* of
     float* actA = reinterpret_cast<float*>(ws + p.actA);
     float* actB = reinterpret_cast<float*>(ws + p.actB);
     float* part = reinterpret_cast<float*>(ws + p.part);
-    float* pooled = reinterpret_cast<float*>(ws + p.pooled);
+    float* pooled = mode == XVEC_MODE_POOLED ? out : reinterpret_cast<float*>(ws + p.pooled);
     float* s6 = reinterpret_cast<float*>(ws + p.seg6);
     float* s7 = reinterpret_cast<float*>(ws + p.seg7);
     const int nh = h->geo[0].n_pad;
@@ -315,7 +317,7 @@ int forward_rows(xvec_handle* h, const float* x_rows, int ldx, const int64_t* of
         HIP_TRY(launch_pack_rows_split(x_rows, p.total, ldx, ldx, in_plane / 2, x16, s));
         in = x16;
     }
-    if ((size_t)p.part_slots * 2 * h->geo[4].n_pad * 4 > 0x7fffffffull)
+    if ((size_t)p.part_slots * 3 * h->geo[4].n_pad * 4 > 0x7fffffffull)
         return fail(XVEC_ERR_ARG, "batch too large: pooling partials exceed 2 GiB; split it");
     for (int l = 0; l < XVEC_NUM_TDNN; ++l) {
         map.cum += h->geo[l].ctx_span;
@@ -338,10 +340,11 @@ int forward_rows(xvec_handle* h, const float* x_rows, int ldx, const int64_t* of
         f.C = XVEC_POOL_CHANNELS;
         f.n_pad = h->geo[4].n_pad;
         f.sub_rows = 32;
-        f.scale = h->vec[4] + f.n_pad;              // the pooling epilogues leave raw sums of relu(z + bias)
+        f.scale = h->vec[4] + f.n_pad;              // the pooling epilogues leave sums of r = relu(z + bias)
         f.shift = h->vec[4] + 2 * f.n_pad;
         HIP_TRY(launch_pool_finalize(f, s));
     }
+    if (mode == XVEC_MODE_POOLED) return XVEC_OK;
     const int xv = h->cfg.x_vector_size, K6 = 2 * XVEC_POOL_CHANNELS;
     // the frame-level activations are dead from here on: layers 1-4's buffers serve as split-K scratch
     float* scr = actA;
@@ -374,7 +377,8 @@ int forward_rows(xvec_handle* h, const float* x_rows, int ldx, const int64_t* of
 // host offsets -> device (stream ordered, via the handle's ring of two pinned staging slots).
 // Synchronous part: only when both slots still hold copies that have not left them (a third ragged
 // call enqueued before the first one's copy ran) does this wait for the older one.
-int stage_offsets(xvec_handle* h, const int64_t* offs_host, int B, int64_t* dev, hipStream_t s) {
+int stage_offsets(xvec_handle* h, const int64_t* offs_host, const int32_t* lengths_host, int B, int64_t* dev,
+                  hipStream_t s) {
     const size_t n = (size_t)B + 1;
     const int slot = h->offs_next;
     h->offs_next ^= 1;
@@ -382,8 +386,14 @@ int stage_offsets(xvec_handle* h, const int64_t* offs_host, int B, int64_t* dev,
         HIP_TRY(hipEventSynchronize(h->offs_evt[slot]));
         h->offs_pending[slot] = false;
     }
-    memcpy(h->offs_pinned[slot], offs_host, n * 8);
-    HIP_TRY(hipMemcpyAsync(dev, h->offs_pinned[slot], n * 8, hipMemcpyHostToDevice, s));
+    int64_t* pin = h->offs_pinned[slot];        // free: its last copy has left it
+    if (offs_host) {
+        memcpy(pin, offs_host, n * 8);
+    } else {                                    // prefix sum of the lengths, built in place (no host allocation)
+        pin[0] = 0;
+        for (int i = 0; i < B; ++i) pin[i + 1] = pin[i] + lengths_host[i];
+    }
+    HIP_TRY(hipMemcpyAsync(dev, pin, n * 8, hipMemcpyHostToDevice, s));
     HIP_TRY(hipEventRecord(h->offs_evt[slot], s));
     h->offs_pending[slot] = true;
     return XVEC_OK;
@@ -393,7 +403,7 @@ int common_checks(xvec_handle* h, const void* x, int B, int mode, int dtype, con
     if (!h) return fail(XVEC_ERR_ARG, "null handle");
     if (!x || !out || !ws) return fail(XVEC_ERR_ARG, "null tensor pointer");
     if (B < 1 || B > kMaxUtts) return fail(XVEC_ERR_ARG, "B must be in [1, %d] (got %d); split larger batches", kMaxUtts, B);
-    if (mode != XVEC_MODE_LOGITS && mode != XVEC_MODE_XVEC6 && mode != XVEC_MODE_XVEC7)
+    if (mode != XVEC_MODE_LOGITS && mode != XVEC_MODE_XVEC6 && mode != XVEC_MODE_XVEC7 && mode != XVEC_MODE_POOLED)
         return fail(XVEC_ERR_ARG, "unknown mode %d", mode);
     if (dtype != XVEC_F32 && dtype != XVEC_BF16 && dtype != XVEC_BF16X3) return fail(XVEC_ERR_ARG, "unknown dtype %d", dtype);
     if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(ws) & 255))
@@ -579,16 +589,7 @@ int xvec_forward(xvec_handle* h, const float* x, const int32_t* lengths_host, in
     const Plan p = make_plan(h, total, B);
     if (workspace_bytes < p.bytes)
         return fail(XVEC_ERR_WORKSPACE, "workspace too small: %zu < %zu", workspace_bytes, p.bytes);
-    {
-        // offsets built directly in the pinned buffer would race with a pending copy: build on stack/heap
-        int64_t* tmp = new (std::nothrow) int64_t[(size_t)B + 1];
-        if (!tmp) return fail(XVEC_ERR_STATE, "out of host memory");
-        tmp[0] = 0;
-        for (int i = 0; i < B; ++i) tmp[i + 1] = tmp[i] + lengths_host[i];
-        rc = stage_offsets(h, tmp, B, reinterpret_cast<int64_t*>(ws + p.offs), s);
-        delete[] tmp;
-        if (rc) return rc;
-    }
+    if ((rc = stage_offsets(h, nullptr, lengths_host, B, reinterpret_cast<int64_t*>(ws + p.offs), s))) return rc;
     const int64_t* offs_dev = reinterpret_cast<const int64_t*>(ws + p.offs);
     float* xp = reinterpret_cast<float*>(ws + p.xpad);
     {
@@ -618,7 +619,7 @@ int xvec_forward_packed(xvec_handle* h, const float* x_packed, const int64_t* of
     const Plan p = make_plan(h, total, B);
     if (workspace_bytes < p.bytes)
         return fail(XVEC_ERR_WORKSPACE, "workspace too small: %zu < %zu", workspace_bytes, p.bytes);
-    if ((rc = stage_offsets(h, offsets_host, B, reinterpret_cast<int64_t*>(ws + p.offs), s))) return rc;
+    if ((rc = stage_offsets(h, offsets_host, nullptr, B, reinterpret_cast<int64_t*>(ws + p.offs), s))) return rc;
     const int64_t* offs_dev = reinterpret_cast<const int64_t*>(ws + p.offs);
     const float* rows = x_packed;
     const int C = h->cfg.input_size;
@@ -654,7 +655,9 @@ int xvec_tdnn_layer(xvec_handle* h, int layer, const float* x, int32_t B, int32_
     const bool in16 = b16 || x3;
     // stage the compact input into the layer's native row layout (stride = producer's n_pad)
     const int ldx = (layer == 0) ? h->cin_pad : h->geo[layer - 1].n_pad;
-    void* xin = ws + (layer == 0 ? (in16 ? p.x16 : p.xpad) : p.actA);
+    // (plain bf16 layer 1 reads fp32 rows and rounds them itself, exactly as in xvec_forward)
+    const bool rows16 = in16 && !(b16 && layer == 0);
+    void* xin = ws + (layer == 0 ? (rows16 ? p.x16 : p.xpad) : p.actA);
     int64_t x_plane = 0;
     if (x3) {   // fp32 rows first (padding to ldx), then the hi/lo split; bf16x3 returns fp32 directly
         void* x32 = ws + p.actB;
@@ -662,10 +665,10 @@ int xvec_tdnn_layer(xvec_handle* h, int layer, const float* x, int32_t B, int32_
         x_plane = p.rows_alloc * (int64_t)ldx * 2;
         HIP_TRY(launch_pack_rows_split(static_cast<const float*>(x32), p.total, ldx, ldx, x_plane / 2, xin, s));
     } else {
-        HIP_TRY(launch_pack_rows(x, nullptr, B, T, g.src_cin, ldx, xin, in16, s));
+        HIP_TRY(launch_pack_rows(x, nullptr, B, T, g.src_cin, ldx, xin, rows16, s));
     }
     void* yflat = ws + (layer == 4 || x3 ? p.act5 : p.actB);
-    const TdnnVariant v = layer == 0 ? (b16 ? TdnnVariant::kBf16First : x3 ? TdnnVariant::kBf16FirstToF32 : TdnnVariant::kF32First)
+    const TdnnVariant v = layer == 0 ? (b16 ? TdnnVariant::kBf16FirstSrc32 : x3 ? TdnnVariant::kBf16FirstToF32 : TdnnVariant::kF32First)
                                      : (b16 ? TdnnVariant::kBf16 : x3 ? TdnnVariant::kBf16ToF32 : TdnnVariant::kF32);
     RowMap map;
     map.offsets = nullptr;
@@ -676,6 +679,59 @@ int xvec_tdnn_layer(xvec_handle* h, int layer, const float* x, int32_t B, int32_
     int rc = run_tdnn(h, layer, v, xin, ldx, p.total, yflat, (int64_t)B * To, map, nullptr, s, x3, x_plane, 0);
     if (rc) return rc;
     HIP_TRY(launch_unpack_rows(yflat, b16, g.n_pad, B, To, To, g.cout, y, s));
+    return XVEC_OK;
+}
+
+int xvec_tdnn_pool_layer(xvec_handle* h, const float* x, int32_t B, int32_t T, int dtype, float* out, void* workspace,
+                         size_t workspace_bytes, xvec_stream stream) {
+    const int layer = XVEC_NUM_TDNN - 1;
+    if (!h) return fail(XVEC_ERR_ARG, "null handle");
+    if (!x || !out || !workspace) return fail(XVEC_ERR_ARG, "null tensor pointer");
+    if (dtype != XVEC_F32 && dtype != XVEC_BF16 && dtype != XVEC_BF16X3) return fail(XVEC_ERR_ARG, "unknown dtype %d", dtype);
+    if (!h->tdnn_loaded[layer]) return fail(XVEC_ERR_STATE, "time_context_layers.%d weights not loaded", layer);
+    DeviceGuard guard;
+    HIP_TRY(guard.enter(h->cfg.device));
+    const TdnnGeom& g = h->geo[layer];
+    if (B < 1 || B > kMaxUtts || T <= g.ctx_span) return fail(XVEC_ERR_ARG, "need 1<=B<=%d and T>%d (got B=%d T=%d)", kMaxUtts, g.ctx_span, B, T);
+    const Plan p = make_plan(h, (int64_t)B * T, B);
+    if (workspace_bytes < p.bytes)
+        return fail(XVEC_ERR_WORKSPACE, "workspace too small: %zu < %zu", workspace_bytes, p.bytes);
+    if ((size_t)p.part_slots * 3 * g.n_pad * 4 > 0x7fffffffull)
+        return fail(XVEC_ERR_ARG, "batch too large: pooling partials exceed 2 GiB; split it");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    char* ws = static_cast<char*>(workspace);
+    const bool x3 = dtype == XVEC_BF16X3, in16 = x3 || dtype == XVEC_BF16;
+    // the input in the layer's native row layout (the producer's n_pad; bf16 / two bf16 planes as in xvec_forward)
+    const int ldx = h->geo[layer - 1].n_pad;
+    void* xin = ws + p.actA;
+    int64_t x_plane = 0;
+    if (x3) {
+        void* x32 = ws + p.actB;
+        HIP_TRY(launch_pack_rows(x, nullptr, B, T, g.src_cin, ldx, x32, false, s));
+        x_plane = p.rows_alloc * (int64_t)ldx * 2;
+        HIP_TRY(launch_pack_rows_split(static_cast<const float*>(x32), p.total, ldx, ldx, x_plane / 2, xin, s));
+    } else {
+        HIP_TRY(launch_pack_rows(x, nullptr, B, T, g.src_cin, ldx, xin, in16, s));
+    }
+    RowMap map;
+    map.offsets = nullptr;
+    map.n_utts = B;
+    map.fixed_T = T;
+    map.cum = g.ctx_span;
+    float* part = reinterpret_cast<float*>(ws + p.part);
+    int rc = run_tdnn(h, layer, in16 ? TdnnVariant::kBf16Pool : TdnnVariant::kF32Pool, xin, ldx, 0, nullptr,
+                      (int64_t)B * (T - g.ctx_span), map, part, s, x3, x_plane, 0);
+    if (rc) return rc;
+    PoolFinalizeArgs f;
+    f.part = part;
+    f.out = out;
+    f.map = map;
+    f.C = XVEC_POOL_CHANNELS;
+    f.n_pad = g.n_pad;
+    f.sub_rows = 32;
+    f.scale = h->vec[layer] + f.n_pad;
+    f.shift = h->vec[layer] + 2 * f.n_pad;
+    HIP_TRY(launch_pool_finalize(f, s));
     return XVEC_OK;
 }
 
@@ -705,6 +761,13 @@ int xvec_affine(xvec_handle* h, int which, const float* x, int32_t M, int relu, 
     HIP_TRY(guard.enter(h->cfg.device));
     HIP_TRY(launch_affine_f32(x, h->affW[i], h->affB[i], y, M, h->affN[i], h->affK[i], relu,
                               static_cast<hipStream_t>(stream)));
+    return XVEC_OK;
+}
+
+int xvec_get_dispatch(const xvec_handle* h, int* kernels, int* n) {
+    if (!h || !kernels || !n) return fail(XVEC_ERR_ARG, "null argument");
+    for (int i = 0; i < XVEC_NUM_TDNN; ++i) kernels[i] = h->last_kernel[i];
+    *n = XVEC_NUM_TDNN;
     return XVEC_OK;
 }
 

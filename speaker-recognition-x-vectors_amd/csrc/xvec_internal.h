@@ -99,7 +99,7 @@ struct TdnnArgs {
     RowMap out_map;           // row layout of THIS layer's output
     int span;                 // frames this layer consumes (c[-1]-c[0]): input row = p + u(p)*span
     // fused statistics-pooling epilogue (layer 5)
-    float* pool_part;         // [slots][2][n_pad] raw sums (sum r, sum r^2), r = relu(z + bias), per (32-row group, utterance)
+    float* pool_part;         // [slots][3][n_pad]: pivot K | sum (r-K) | sum (r-K)^2, r = relu(z + bias), per (32-row group, utterance)
     // bf16x3 (fp32 values carried as two bf16 planes hi + lo, three bf16 products per k-step:
     // x_hi*W_hi + x_hi*W_lo + x_lo*W_hi).  terms == 2: X has a lo plane x_plane_bytes after the hi
     // plane and Wf holds, per chunk, the W_hi fragments followed by the W_lo fragments.
@@ -127,9 +127,9 @@ hipError_t launch_tdnn(const TdnnArgs& a, TdnnVariant v, hipStream_t s);
 //   groups_total = ceil(rows / 64) units, blocks_per_col ranges per column (>= 2.2 units each for full speed).
 hipError_t launch_tdnn_pp(const TdnnArgs& a, bool pool, hipStream_t s);
 // Layer 1 of the bf16 path as a streaming kernel (tdnn_first.hip): weights resident in registers, 16-byte stores.
-// Reads TdnnArgs as the 128x128 kernel does (Wf = fragment-major bf16 weights); src32: X holds fp32 rows.
-bool tdnn_first_applicable(const TdnnArgs& a, int es);
-hipError_t launch_tdnn_first(const TdnnArgs& a, bool src32, int num_cu, hipStream_t s);
+// Reads TdnnArgs as the 128x128 kernel does (Wf = fragment-major bf16 weights); X holds the caller's fp32 rows.
+bool tdnn_first_applicable(const TdnnArgs& a);
+hipError_t launch_tdnn_first(const TdnnArgs& a, int num_cu, hipStream_t s);
 // K-tile major bf16 copy of the packed weights for it
 hipError_t launch_pack_tdnn_rows_bf16(const float* W, const TdnnGeom& geo, void* Wr16, hipStream_t s);
 
@@ -142,7 +142,7 @@ struct PoolArgs {
 hipError_t launch_stat_pool(const PoolArgs& a, hipStream_t s);
 
 struct PoolFinalizeArgs {
-    const float* part;       // [slots][2][n_pad]: raw sums (S1, S2) of r = relu(z + bias) per (sub-tile, utterance)
+    const float* part;       // [slots][3][n_pad]: pivot K | sum (r-K) | sum (r-K)^2 of r = relu(z + bias) per (sub-tile, utterance)
     float* out;              // [B][2C]
     RowMap map;              // row layout of the pooled activation (layer 5 output)
     int C, n_pad, sub_rows;

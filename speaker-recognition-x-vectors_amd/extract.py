@@ -86,12 +86,17 @@ def gather_embeddings(local: torch.Tensor, n_total: int, group=None,
 
 
 def extract_sharded(extract_fn: Callable[[torch.Tensor], torch.Tensor], make_batch: Callable[[int, int], torch.Tensor],
-                    n_total: int, batch_size: int = 256, group=None, force_collective: bool = False) -> torch.Tensor:
-    """Utterance-sharded extraction job (BASELINE config 4).
+                    n_total: int, batch_size: int = 256, group=None, force_collective: bool = False,
+                    embed_dim: int = None, device=None) -> torch.Tensor:
+    """Utterance-sharded extraction job (BASELINE configs[3]).
 
     make_batch(lo, hi) returns the device tensor [hi-lo, T, C] for global utterances
     lo..hi-1 (a loader, or an on-device generator in the benchmark); extract_fn is
-    model.extract_x_vec.  Every rank returns the full [n_total, D] matrix."""
+    model.extract_x_vec.  Every rank returns the full [n_total, D] matrix.
+
+    A rank whose block is empty (n_total < world * ceil(n_total / world)) extracts nothing: it joins the
+    all-gather with a [0, D] shard, D = `embed_dim` or, when that is not given, learnt from its peers by one
+    scalar all-reduce (every rank takes part in it, and only when the last rank's block is empty)."""
     import torch.distributed as dist
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -100,11 +105,21 @@ def extract_sharded(extract_fn: Callable[[torch.Tensor], torch.Tensor], make_bat
     for b0 in range(lo, hi, batch_size):
         b1 = min(b0 + batch_size, hi)
         parts.append(extract_fn(make_batch(b0, b1)))
-    if parts:
-        local = torch.cat(parts, 0)
-    else:   # rank without work still has to join the collective: learn D from a peer-sized dummy
-        probe = extract_fn(make_batch(0, 1))
-        local = probe[:0]
+    local = torch.cat(parts, 0) if parts else None
+    last_lo, last_hi = shard_bounds(n_total, world - 1, world)
+    if world > 1 and last_hi <= last_lo:                       # some rank has no utterances: same answer on every rank
+        if device is None:
+            device = local.device if local is not None else (
+                torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu"))
+        D = embed_dim
+        if D is None:
+            t = torch.tensor([local.shape[1] if local is not None else 0], dtype=torch.int64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+            D = int(t.item())
+        if local is None:
+            local = torch.zeros((0, D), dtype=torch.float32, device=device)
+    if local is None:
+        raise ValueError("extract_sharded: nothing to extract (n_total < 1)")
     return gather_embeddings(local, n_total, group, force=force_collective)
 
 

@@ -15,13 +15,22 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# XVEC_LIB: development override (A/B runs of two builds on one GPU box); the default is the in-tree build
-LIB_PATH = os.environ.get("XVEC_LIB") or os.path.join(_HERE, "libxvec_hip.so")
+# XVEC_LIB: development override (A/B runs of two builds on one GPU box; diagnostic builds under build/).  It must
+# be an absolute path and is announced on stderr, so a stray library can never be picked up silently; the
+# default -- and the only thing that ships -- is the in-tree build.
+_override = os.environ.get("XVEC_LIB")
+if _override:
+    import sys
+    if not os.path.isabs(_override):
+        raise ImportError(f"XVEC_LIB={_override!r} must be an absolute path (unset it to load the in-tree library)")
+    print(f"[xvector_amd] XVEC_LIB override: loading {_override}", file=sys.stderr)
+LIB_PATH = _override or os.path.join(_HERE, "libxvec_hip.so")
 
 OK, ERR_ARG, ERR_HIP, ERR_STATE, ERR_WORKSPACE = 0, 1, 2, 3, 4
 F32, BF16, BF16X3 = 0, 1, 2
-MODE_LOGITS, MODE_XVEC6, MODE_XVEC7 = 0, 6, 7
+MODE_LOGITS, MODE_POOLED, MODE_XVEC6, MODE_XVEC7 = 0, 5, 6, 7
 SEG6, SEG7, OUTPUT = 6, 7, 8
+KERNEL_NAMES = {0: None, 1: "tile128", 2: "pp", 3: "first"}      # XVEC_KERNEL_*
 TIMING_NAMES = ("tdnn1", "tdnn2", "tdnn3", "tdnn4", "tdnn5_pool", "pool_finalize",
                 "segment6", "segment7", "output", "pack")
 
@@ -66,10 +75,12 @@ _SIGS = {
     "xvec_forward_packed": (C.c_int, [_vp, _f32p, C.POINTER(_i64), _i32, C.c_int, C.c_int, _f32p, _vp,
                                       C.c_size_t, _vp]),
     "xvec_tdnn_layer": (C.c_int, [_vp, C.c_int, _f32p, _i32, _i32, C.c_int, _f32p, _vp, C.c_size_t, _vp]),
+    "xvec_tdnn_pool_layer": (C.c_int, [_vp, _f32p, _i32, _i32, C.c_int, _f32p, _vp, C.c_size_t, _vp]),
     "xvec_stat_pool": (C.c_int, [_f32p, _vp, _i32, _i32, _i32, _f32p, _vp]),
     "xvec_affine": (C.c_int, [_vp, C.c_int, _f32p, _i32, C.c_int, _f32p, _vp]),
     "xvec_set_profiling": (C.c_int, [_vp, C.c_int]),
     "xvec_get_timings": (C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
+    "xvec_get_dispatch": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "xvec_mfcc_create": (C.c_int, [C.POINTER(MfccCfg), C.POINTER(_vp)]),
     "xvec_mfcc_destroy": (None, [_vp]),
     "xvec_mfcc_last_error": (C.c_char_p, []),

@@ -164,7 +164,10 @@ class XVectorModel(nn.Module):
         main.py:213) without Lightning installed: reads `ckpt['hyper_parameters']` (what
         `save_hyperparameters()` stored, main.py:56) and `ckpt['state_dict']` from a reference
         `.ckpt` file.  Classes the pickle refers to but that are not importable here (Lightning's
-        AttributeDict, callbacks) are read as plain dicts."""
+        AttributeDict, callbacks) are read as plain dicts.
+
+        SECURITY: a .ckpt is a pickle and is loaded with weights_only=False, exactly as Lightning's own loader does --
+        un-pickling runs code named by the file.  Only load checkpoints you trust."""
         import pickle
 
         class _Lenient(pickle.Unpickler):
@@ -296,6 +299,9 @@ class XVectorModel(nn.Module):
         per = max_utts if max_frames is None else min(max_utts, max_frames // T)
         if per < 1:
             raise ValueError(f"one utterance of {T} frames exceeds the {max_frames} frames a call can hold in this precision")
+        # pooling partials of one call stay below 2 GiB: (frames/32 + utterances + 1) slots x 3 planes x 1536 x 4 bytes
+        # (a single utterance beyond that -- 3.7 M frames, ten hours -- is refused by the library)
+        per = max(1, min(per, int((0x7FFFFFFF // (3 * 1536 * 4) - 2) / (T / 32.0 + 1.0))))
         return [(lo, min(lo + per, B)) for lo in range(0, B, per)]
 
     def _run(self, x: torch.Tensor, mode: int, lengths=None, workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -322,11 +328,19 @@ class XVectorModel(nn.Module):
             ws, ws_bytes = workspace.data_ptr(), workspace.numel()
         else:
             ws, ws_bytes = eng.ensure_workspace(total, B)
-        n_out = self.hparams["num_classes"] if mode == _hip.MODE_LOGITS else self.hparams["x_vector_size"]
+        n_out = (self.hparams["num_classes"] if mode == _hip.MODE_LOGITS else
+                 2 * POOL_CHANNELS if mode == _hip.MODE_POOLED else self.hparams["x_vector_size"])
         out = torch.empty((B, n_out), dtype=torch.float32, device=x.device)
         with torch.cuda.device(x.device):
-            _hip.check(_hip.lib.xvec_forward(eng.h, x.data_ptr(), arr, B, T, mode, _DTYPES[self.precision],
-                                             out.data_ptr(), ws, ws_bytes, _stream_ptr(x.device)))
+            rc = _hip.lib.xvec_forward(eng.h, x.data_ptr(), arr, B, T, mode, _DTYPES[self.precision],
+                                       out.data_ptr(), ws, ws_bytes, _stream_ptr(x.device))
+        if rc == _hip.ERR_ARG and B > 1 and workspace is None and "split" in _hip.last_error():
+            # one of the library's per-call size limits (32-bit row offsets, pooling partials < 2 GiB, 30-bit bf16x3
+            # planes: include/xvec_hip.h) that _call_ranges did not foresee: two calls of half the batch each
+            half = B // 2
+            return torch.cat([self._run(x[:half], mode, None if lens is None else lens[:half]),
+                              self._run(x[half:], mode, None if lens is None else lens[half:])], 0)
+        _hip.check(rc)
         return out
 
     # ------------------------------------------------------------------ reference surface
@@ -357,6 +371,12 @@ class XVectorModel(nn.Module):
         segment_layer6 (x_vec_extract_layer == 6 or any other value) or segment_layer7 (== 7)."""
         mode = _hip.MODE_XVEC7 if self.x_vec_extract_layer == 7 else _hip.MODE_XVEC6
         return self._run(x, mode, lengths)
+
+    def pooled(self, x, lengths=None):
+        """`self.stat_pool(self.time_context_layers(x))` as forward / extract_x_vec compute it (main.py:68-69,
+        83-84): [B, 3000] = mean ‖ unbiased std of the layer-5 output, which never exists in memory here (the
+        pooling sums are formed in layer 5's epilogue)."""
+        return self._run(x, _hip.MODE_POOLED, lengths)
 
     def graphed(self, example: torch.Tensor, logits: bool = False) -> "GraphedPath":
         """The whole path for one fixed shape [B, T, C] as ONE hipGraph (fixed-length batches only).
@@ -406,6 +426,21 @@ class XVectorModel(nn.Module):
                                                 y.data_ptr(), ws, ws_bytes, _stream_ptr(x.device)))
         return y
 
+    def pooled_last_layer(self, x: torch.Tensor) -> torch.Tensor:
+        """`self.stat_pool(self.time_context_layers[4](x))` on a given x[B,T,hidden]: the fused layer-5 + pooling
+        kernel alone (per-stage entry for the parity tests; main.py:44,59-63)."""
+        x = self._prep_input(x, "pooled_last_layer")
+        B, T, Cin = x.shape
+        if Cin != self.hparams["hidden_size"]:
+            raise ValueError(f"pooled_last_layer: expected {self.hparams['hidden_size']} channels, got {Cin}")
+        eng = self._engine(x.device)
+        ws, ws_bytes = eng.ensure_workspace(B * T, B)
+        out = torch.empty((B, 2 * POOL_CHANNELS), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _hip.check(_hip.lib.xvec_tdnn_pool_layer(eng.h, x.data_ptr(), B, T, _DTYPES[self.precision], out.data_ptr(),
+                                                     ws, ws_bytes, _stream_ptr(x.device)))
+        return out
+
     def affine(self, which: str, x: torch.Tensor, relu: bool = False) -> torch.Tensor:
         """segment_layer6 / segment_layer7 / output as a stand-alone HIP GEMM (+ReLU)."""
         ids = {"segment_layer6": _hip.SEG6, "segment_layer7": _hip.SEG7, "output": _hip.OUTPUT}
@@ -435,6 +470,15 @@ class XVectorModel(nn.Module):
         n = C.c_int(0)
         _hip.check(_hip.lib.xvec_get_timings(eng.h, buf, C.byref(n)))
         return {name: float(buf[i]) for i, name in enumerate(_hip.TIMING_NAMES[:n.value])}
+
+    def last_dispatch(self, device=None) -> list:
+        """Kernel family the last launch of each frame-level layer went to: "tile128" | "pp" | "first" | None."""
+        dev = torch.device(device) if device is not None else next(self.parameters()).device
+        eng = self._engine(dev)
+        buf = (C.c_int * 8)()
+        n = C.c_int(0)
+        _hip.check(_hip.lib.xvec_get_dispatch(eng.h, buf, C.byref(n)))
+        return [_hip.KERNEL_NAMES.get(int(buf[i])) for i in range(n.value)]
 
     # ------------------------------------------------------------------ caller shims (main.py:135-146)
     def test_step(self, batch, batch_index=0):

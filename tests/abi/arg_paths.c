@@ -51,6 +51,7 @@ int main(void) {
     EXPECT(xvec_forward(0, buf, 0, 1, 32, XVEC_MODE_XVEC6, XVEC_F32, buf, buf, sizeof buf, 0) == XVEC_ERR_ARG);
     EXPECT(xvec_forward_packed(0, buf, 0, 1, XVEC_MODE_XVEC6, XVEC_F32, buf, buf, sizeof buf, 0) == XVEC_ERR_ARG);
     EXPECT(xvec_tdnn_layer(0, 0, buf, 1, 32, XVEC_F32, buf, buf, sizeof buf, 0) == XVEC_ERR_ARG);
+    EXPECT(xvec_tdnn_pool_layer(0, buf, 1, 32, XVEC_F32, buf, buf, sizeof buf, 0) == XVEC_ERR_ARG);
     EXPECT(xvec_affine(0, XVEC_SEG6, buf, 1, 0, buf, 0) == XVEC_ERR_ARG);
     EXPECT(xvec_set_profiling(0, 1) == XVEC_ERR_ARG);
     EXPECT(xvec_get_timings(0, buf, &n) == XVEC_ERR_ARG);

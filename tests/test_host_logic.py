@@ -257,6 +257,7 @@ def test_call_ranges_split_a_batch_that_one_call_cannot_hold():
     assert R(5000, 300, 1_000_000, 65535) == [(0, 3333), (3333, 5000)]
     assert R(70000, 20, None, 65535) == [(0, 65535), (65535, 70000)]
     assert R(7, 400, 1000, 65535) == [(0, 2), (2, 4), (4, 6), (6, 7)]
+    assert R(20000, 300, None, 65535) == [(0, 11229), (11229, 20000)]     # pooling partials < 2 GiB per call
     with pytest.raises(ValueError, match="exceeds"):
         R(2, 2000, 1000, 65535)
     m = xa.XVectorModel(precision="bf16x3")

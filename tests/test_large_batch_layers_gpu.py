@@ -1,0 +1,204 @@
+"""Whole-tensor parity of the hand-scheduled large-batch kernels (VERDICT r02 / ADVICE r02).
+
+The end-to-end x-vector checks average ~286 frames per output value and were shown blind to sparse row
+corruption (a WAR race and a 128-bit-store hazard both passed them), so here every ELEMENT of every layer's
+output is compared at sizes that dispatch
+  * `pp::tdnn_pp_kernel<false>` (tdnn_pp.hip, store variant: layers 2-4, and layer 5 through the per-layer entry),
+  * `pp::tdnn_pp_kernel<true>` (layer 5 + fused pooling, through `xvec_tdnn_pool_layer`),
+  * `first::tdnn_first_kernel` (tdnn_first.hip, layer 1 reading fp32 rows),
+with every tile height the persistent blocks cut: 63 utterances of 300 frames give blocks of 2 units of 64 frames,
+100 -> 3 (+ masked last unit), 128 -> 5 = 3 + 2, 160 / 256 -> 4-unit tiles, (70, 517) boundaries inside tiles.
+
+Three references per layer, same input to all:
+  1. the fp64 oracle (reference tdnn_layer.py:26-41) at the bf16 bar 1e-2 (norm-wise per frame), element-wise 2e-2;
+  2. the SAME arithmetic on the 128x128 kernel (a second engine created under XVEC_PP=0): both round identical
+     fp32 sums (up to summation order) to bf16, so outputs differ by at most one bf16 ulp on the few elements
+     whose rounding flips -- a corrupted element is tens of ulps away;
+  3. repeat runs are bit-identical (a race shows up as run-to-run differences).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import xvector_oracle as oracle
+from conftest import assert_parity, float_params
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+SHAPES = [(63, 300), (100, 300), (128, 300), (160, 300), (256, 300), (70, 517)]
+
+
+def _model(sd, precision, pp=True):
+    """bf16 model whose engine is created with the large-batch kernels on (default) or off (XVEC_PP=0 is read
+    once per handle in xvec_create)."""
+    import xvector_amd as xa
+    m = xa.XVectorModel(precision=precision)
+    m.load_state_dict(sd)
+    m = m.to(DEV)
+    old = os.environ.get("XVEC_PP")
+    try:
+        if pp:
+            os.environ.pop("XVEC_PP", None)
+        else:
+            os.environ["XVEC_PP"] = "0"
+        m._engine(torch.device(DEV))          # creates the handle now, under this environment
+    finally:
+        if old is None:
+            os.environ.pop("XVEC_PP", None)
+        else:
+            os.environ["XVEC_PP"] = old
+    return m
+
+
+@pytest.fixture(scope="module")
+def models(sd42):
+    return _model(sd42, "bf16", pp=True), _model(sd42, "bf16", pp=False)
+
+
+def _oracle_layer(x_cpu, p64, layer, chunk=32):
+    """fp64 oracle of one layer on fp32 input, a few utterances at a time (memory)."""
+    outs = []
+    for lo in range(0, x_cpu.shape[0], chunk):
+        outs.append(oracle.tdnn_layer(x_cpu[lo:lo + chunk].double(), p64, f"time_context_layers.{layer}.",
+                                      oracle.CONTEXTS[layer]).float())
+    return torch.cat(outs)
+
+
+def _ulp_report(a, b):
+    d = (a.double() - b.double()).abs()
+    return float((d / b.double().abs().clamp_min(1e-3)).max()), int((d > 0).sum())
+
+
+@pytest.mark.parametrize("B,T", SHAPES)
+def test_bf16_every_layer_every_element(gpu_model, sd42, synth, models, B, T):
+    m_pp, m_old = models
+    p64 = oracle.cast_params(float_params(sd42), torch.float64)
+    h = torch.as_tensor(synth.make_mfcc(B, T, seed=1000 + B)).to(DEV)
+    for i in range(5):
+        got = m_pp.time_context_layers[i](h)
+        assert m_pp.last_dispatch()[i] == ("first" if i == 0 else "pp"), "the batch did not reach the large-batch kernel"
+        # (3) determinism
+        assert torch.equal(got, m_pp.time_context_layers[i](h)), f"layer {i}: repeat run differs"
+        # (1) fp64 oracle, every frame
+        ref = _oracle_layer(h.cpu(), p64, i)
+        assert_parity(got, ref, 1e-2, f"bf16 layer {i} B={B} T={T} vs oracle", elem_tol=2e-2)
+        # (2) same arithmetic, other kernel: at most one bf16 ulp (2^-7 relative) on any element
+        old = m_old.time_context_layers[i](h)
+        assert m_old.last_dispatch()[i] == "tile128"
+        assert_parity(got, old, 1e-3, f"bf16 layer {i} B={B} T={T} large-batch vs 128x128 kernel", elem_tol=1e-2)
+        h = gpu_model.time_context_layers[i](h)       # next layer's input: the fp32 path's output
+
+
+@pytest.mark.parametrize("B,T", SHAPES)
+def test_bf16_fused_pooling_layer(gpu_model, sd42, synth, models, B, T):
+    """Layer 5 + statistics pooling (tdnn_pp_kernel<true> + pool_finalize) on a given layer-4 output: against the
+    fp64 oracle's stat_pool(tdnn_layer(x)) and, tightly, against the 128x128 kernel's pooling epilogue (same bf16
+    products, fp32 sums in another order: a single corrupted frame would move a mean by ~1/286 of a value)."""
+    m_pp, m_old = models
+    p64 = oracle.cast_params(float_params(sd42), torch.float64)
+    h = torch.as_tensor(synth.make_mfcc(B, T, seed=2000 + B)).to(DEV)
+    for i in range(4):
+        h = gpu_model.time_context_layers[i](h)
+    got = m_pp.pooled_last_layer(h)
+    assert m_pp.last_dispatch()[4] == "pp"
+    assert torch.equal(got, m_pp.pooled_last_layer(h))
+    old = m_old.pooled_last_layer(h)
+    assert m_old.last_dispatch()[4] == "tile128"
+    assert_parity(got, old, 2e-5, f"pooled B={B} T={T}: large-batch vs 128x128 kernel", elem_tol=1e-4)
+    idx = sorted({0, 1, B // 3, B // 2, B - 2, B - 1})
+    ref = torch.cat([oracle.stat_pool(_oracle_layer(h[j:j + 1].cpu(), p64, 4).double()) for j in idx])
+    assert_parity(got[idx], ref, 1e-2, f"pooled B={B} T={T} vs oracle")
+    assert_parity(got[idx][:, 1500:], ref[:, 1500:], 1e-2, "std half alone")
+    # the fp32 kernel's fused pooling on the same input, every utterance
+    assert_parity(got, gpu_model.pooled_last_layer(h), 1e-2, "vs fp32 fused pooling")
+
+
+@pytest.mark.parametrize("precision,tol", [("fp32", 1e-4), ("bf16x3", 1e-4)])
+def test_fused_pooling_layer_vs_oracle(sd42, synth, gpu_model, precision, tol):
+    """The fp32 / bf16x3 pooling epilogue (tdnn_layer.hip) alone, every utterance against the fp64 oracle,
+    mean half and std half separately (the std half is 5x smaller in norm and would hide behind the means)."""
+    m = gpu_model if precision == "fp32" else _model(sd42, precision)
+    p64 = oracle.cast_params(float_params(sd42), torch.float64)
+    h = torch.as_tensor(synth.make_mfcc(24, 300, seed=77)).to(DEV)
+    for i in range(4):
+        h = gpu_model.time_context_layers[i](h)
+    got = m.pooled_last_layer(h)
+    ref = oracle.stat_pool(_oracle_layer(h.cpu(), p64, 4).double())
+    assert_parity(got[:, :1500], ref[:, :1500], tol, f"{precision} pooled means")
+    assert_parity(got[:, 1500:], ref[:, 1500:], tol, f"{precision} pooled stds")
+
+
+def _ill_conditioned_sd(sd42):
+    """Layer 5 with bias +50 and weights x 0.01: every post-ReLU channel is always on with std/mean ~ 1e-4..1e-3
+    (a saturated channel of a trained network).  torch.std (main.py:61) is two-pass and does not care."""
+    sd = {k: v.clone() for k, v in sd42.items()}
+    sd["time_context_layers.4.linear.weight"] *= 0.01
+    sd["time_context_layers.4.linear.bias"] = torch.full_like(sd["time_context_layers.4.linear.bias"], 50.0)
+    return sd
+
+
+@pytest.mark.parametrize("precision,B,tol", [("fp32", 12, 1e-4), ("bf16x3", 12, 1e-4), ("bf16", 12, 1e-2), ("bf16", 96, 1e-2)])
+def test_ill_conditioned_pooling_through_the_fused_path(sd42, synth, precision, B, tol):
+    """|mean| >> std through layer 5's epilogue + pool_finalize (not the stand-alone stat_pool kernel): the pooled
+    statistics AND the x-vectors against the fp64 oracle.  Round 2's raw fp32 sums (sum r, sum r^2) lose
+    1e-7*(mean/std)^2 of the variance -- everything, here."""
+    sd = _ill_conditioned_sd(sd42)
+    m = _model(sd, precision)
+    p64 = oracle.cast_params(float_params(sd), torch.float64)
+    x = torch.as_tensor(synth.make_mfcc(B, 300, seed=5))
+    idx = list(range(B)) if B <= 12 else sorted({0, 1, B // 2, B - 1})
+    h64 = oracle.time_context_layers(x[idx].double(), p64)
+    ref = oracle.stat_pool(h64)
+    ratio = float((ref[:, :1500].abs() / ref[:, 1500:].clamp_min(1e-30)).median())
+    assert ratio > 100, f"test is not ill-conditioned (median |mean|/std = {ratio:.1f})"
+    got = m.pooled(x.to(DEV))[idx]
+    assert_parity(got[:, :1500], ref[:, :1500], tol, f"{precision} means, |mean|/std ~ {ratio:.0f}")
+    # bf16 rounds layer 4's output (layer 5's input) to 8 bits: the deviations r - mean inherit that 4e-3 noise
+    assert_parity(got[:, 1500:], ref[:, 1500:], tol, f"{precision} stds, |mean|/std ~ {ratio:.0f}",
+                  elem_tol=4e-2 if precision == "bf16" else None)
+    xv = oracle.extract_x_vec(x[idx].double(), p64)
+    assert_parity(m.extract_x_vec(x.to(DEV))[idx], xv, tol, f"{precision} x-vectors")
+    # ragged: the straddling groups' shared pivot
+    lens = np.random.default_rng(B).integers(150, 301, B)
+    gr = m.pooled(x.to(DEV), lengths=lens.tolist())[idx]
+    rr = torch.cat([oracle.stat_pool(oracle.time_context_layers(x[j:j + 1, :int(lens[j])].double(), p64)) for j in idx])
+    assert_parity(gr[:, :1500], rr[:, :1500], tol, f"{precision} ragged means")
+    assert_parity(gr[:, 1500:], rr[:, 1500:], tol, f"{precision} ragged stds", elem_tol=4e-2 if precision == "bf16" else None)
+
+
+@pytest.mark.parametrize("B", [64, 200])
+def test_bf16_ragged_large_batches_pooled(gpu_model, sd42, synth, models, B):
+    """Ragged batches on the large-batch kernels (set_rows<RAGGED>, tdnn_first_kernel<true>, the pooling cursor on
+    loaded offsets): pooled statistics of every utterance against the 128x128 kernels (tight) and the fp32 path."""
+    m_pp, m_old = models
+    lens = np.random.default_rng(B).integers(200, 601, B)
+    x = torch.as_tensor(synth.make_mfcc(B, int(lens.max()), seed=3000 + B)).to(DEV)
+    got = m_pp.pooled(x, lengths=lens.tolist())
+    assert m_pp.last_dispatch() == ["first", "pp", "pp", "pp", "pp"]
+    assert torch.equal(got, m_pp.pooled(x, lengths=lens.tolist()))
+    assert_parity(got, m_old.pooled(x, lengths=lens.tolist()), 2e-4, "ragged pooled: large-batch vs 128x128 kernels",
+                  elem_tol=2e-3)
+    assert_parity(got, gpu_model.pooled(x, lengths=lens.tolist()), 1e-2, "ragged pooled vs fp32", elem_tol=2e-2)
+    for j in (0, B // 2, B - 1):            # and each utterance alone, un-padded (the reference's definition)
+        n = int(lens[j])
+        alone = m_pp.pooled(x[j:j + 1, :n])
+        assert_parity(got[j:j + 1], alone, 2e-4, f"utt {j} ragged vs alone", elem_tol=2e-3)
+
+
+def test_bf16_bench_batch_sampled_rows_vs_oracle(sd42, synth, models):
+    """configs[4] at its own size (B=256, T=300) against the reference's arithmetic, not only against this
+    library's fp32 path: sampled utterances through the fp32 CPU oracle."""
+    m_pp, _ = models
+    x = synth.make_mfcc(256, 300, seed=31)
+    out = m_pp.extract_x_vec(torch.as_tensor(x).to(DEV))
+    idx = [0, 1, 63, 64, 127, 128, 200, 255]
+    with torch.no_grad():
+        ref = oracle.extract_x_vec(torch.from_numpy(x[idx]), float_params(sd42))
+    assert_parity(out[idx], ref, 1e-2, "bf16 B=256 sampled rows vs oracle")
+    logits = m_pp(torch.as_tensor(x).to(DEV))
+    with torch.no_grad():
+        refl = oracle.forward(torch.from_numpy(x[idx]), float_params(sd42))
+    assert_parity(logits[idx], refl, 1e-2, "bf16 B=256 sampled logits vs oracle")

@@ -178,6 +178,11 @@ def main():
         args.gpus = world
     if args.dry_run:
         return dry_run(args, world, rank)
+    # stdout carries exactly ONE line, the JSON: whatever a library prints there while the ranks run (RCCL's version
+    # banner at communicator creation, for one) goes to stderr; the line itself is written to the saved descriptor
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import torch.distributed as dist
     import xvector_amd as xa
@@ -504,7 +509,8 @@ def main():
                           f"value = the fastest of the four legs ({best}: B={head.get('batch', '?')}, {head['threads']} "
                           f"thread(s)); {secs:.1f} s of CPU work in all",
                 "legs": legs}
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if collective:
         dist.destroy_process_group()
 

@@ -1,0 +1,844 @@
+// Frame-level TDNN layer, bf16 operands / fp32 accumulation, for the large batches of the bf16 path
+// (BASELINE configs[4]) -- the mapping of tdnn_pp.hip on v_mfma_f32_16x16x32_bf16 instead of
+// v_mfma_f32_32x32x16_bf16, at the SAME wave output tile (MR x 32 frames x 64 channels), the same LDS image,
+// DMA schedule, barriers and counted waits.  Why: the bf16 path is power-limited on this chip and the
+// clock the chip holds under load depends on the MFMA shape (MI355X_MICROARCH.md, DVFS give-back item 7: ~1.12-1.15x
+// the FLOP/s on random data at equal cycles per FLOP).  What differs from tdnn_pp.hip:
+//   * fragments: lane (c = l & 15, q = l >> 4) reads row 16*fb + c of a 32-row block, 16-byte chunk 4*s + q of
+//     k-step s (two k-steps of 32 per K-tile); the XOR swizzle (row >> 1) & 7 of the image is conflict-free for this
+//     ds_read_b128 pattern too (checked per 16-lane service group);
+//   * accumulators: per 32-frame acc row 2 frame blocks x 4 channel blocks of 16x16 (4 registers each: frame
+//     4*q + e of the block, channel c of the channel block);
+//   * weights: row 16*cb + c of a wave's 64-channel block holds channel 4*c + cb (pack.hip, shape 16), so a lane's
+//     four accumulators of a frame hold four ADJACENT channels: the store epilogue writes 8 bytes per lane = whole
+//     128-byte row segments of four frames per instruction; the pooling epilogue reduces over the four lane quads
+//     with v_permlane16_swap + v_permlane32_swap and writes all three planes of a partial with one 16-byte store.
+// The rest of this header is tdnn_pp.hip's.
+//
+// The same implicit GEMM as tdnn_layer.hip (tdnn_layer.py:26-41 of the
+// reference: context gather -> Linear -> ReLU -> eval BatchNorm, optional fused statistics pooling,
+// main.py:59-63) with a machine mapping built for the bf16 matrix rate.
+//
+// Why a second mapping.  The 128x128-tile kernel of tdnn_layer.hip moves 512 B from L2 per
+// v_mfma_f32_32x32x16_bf16; at the bf16 rate that is ~52 B/clk per CU against the ~64 B/clk the
+// L2 -> CU path delivers, so loads and MFMAs add up instead of overlapping (DESIGN.md 8 [4]).  Here:
+//   * ONE 512-thread block per CU, tile = up to 256 frames x 256 channels, K in 64-wide tiles
+//     (128-byte rows): 256 B per MFMA, half the L2 traffic.
+//   * both operands go global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds: no staging registers,
+//     no ds_write), 1-KiB pieces of 8 rows x 128 B; the 16-byte-chunk XOR swizzle that makes the
+//     ds_read_b128 fragment reads conflict-free is applied on the SOURCE address (the LDS image of
+//     a DMA piece is lane-linear).  Two 64-KiB LDS buffers (K-tile parity), refilled slot by slot
+//     two K-tiles ahead behind COUNTED s_waitcnt vmcnt -- the queue is never drained in the loop.
+//   * 8 waves = 2 groups (frames halves) x 4 (64-channel columns); wave tile = MR x 2 accumulators
+//     of 32x32 (MR = 2, 3 or 4 per tile: 128, 192 or 256 frames).  The two waves of a SIMD belong to
+//     different groups and run one barrier apart ("ping-pong"): while one issues its 16 MFMAs of a
+//     phase, the other reads its next fragments from LDS and issues its DMA pieces, then they swap.
+//     A phase = 2 accumulator rows x 2 columns x 4 k-steps; 2 phases per K-tile.
+//   * persistent: a block owns a contiguous range of 64-frame units of one 256-channel column and
+//     cuts it into tiles of 4, 3 or 2 units, as equal as possible (a partial round of fixed 256-row
+//     tiles would idle a quarter of the chip at B=256: 584 tiles over 256 CUs).
+//   * epilogues: frames in the accumulator's registers, the channel on the lane, and a lane's two accumulators
+//     hold ADJACENT channels (a row permutation of the packed weights, pack.hip); bias / scale / shift of those
+//     two channels are 8-byte reads from a 3-KiB LDS table.  Store variant: ReLU + folded BatchNorm, v_cvt_pk_bf16_f32 joins the two
+//     columns and a store instruction writes two whole 128-byte row segments.  Pooling variant (layer 5): pivoted
+//     sums (K, sum (r-K), sum (r-K)^2) of r = relu(z + bias) per (32-frame group, utterance), 8-byte pairs per lane.
+// The next tile's first K-tiles are requested before the epilogue, so the DMA flies under it.
+#include "tdnn_common.h"
+
+namespace xvec {
+namespace pp16 {
+
+constexpr int kRowB = 128;                        // one K-tile slab of one row: 64 bf16
+constexpr int kAccRowB = 32 * kRowB;              // 32 frames: 4 KiB = 4 DMA pieces
+constexpr int kABytes = 2 * 4 * kAccRowB;         // [group][acc row][32 frames]: 32 KiB
+constexpr int kWBytes = 256 * kRowB;              // 256 channels: 32 KiB = 32 DMA pieces
+constexpr int kBufBytes = kABytes + kWBytes;      // 64 KiB
+constexpr int kConstOff = 2 * kBufBytes;
+constexpr int kConstBytes = 3 * 256 * 4;          // bias | scale | shift of the block's 256 channels, natural order
+constexpr int kLdsBytes = kConstOff + kConstBytes;
+constexpr int kThreads = 512;
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_ptr;
+
+__device__ __forceinline__ i32x4 make_srd(const void* p) {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    i32x4 d;
+    d.x = (int)__builtin_amdgcn_readfirstlane((unsigned)v);
+    d.y = (int)(__builtin_amdgcn_readfirstlane((unsigned)(v >> 32)) & 0xffffu);   // stride 0
+    d.z = 0x7fffffff;                                                            // num_records (bytes)
+    d.w = 0x00020000;
+    return d;
+}
+
+// One DMA piece: 64 lanes x 16 B from per-lane source offsets to 1 KiB of LDS at `dst` (wave
+// uniform).  Inline asm on purpose: hipcc would wait vmcnt(0) for the builtin form before the
+// next ds_read; this way the pieces are invisible to its bookkeeping and are waited for by hand
+// (counted vmcnt before the barrier that publishes them).
+__device__ __forceinline__ void dma16(const i32x4& rsrc, unsigned dst, int voff, int soff) {
+    // dst / soff / rsrc are SALU results (no VALU-written SGPR feeds the load: no wait states needed
+    // beyond the one after the M0 write); M0 is declared clobbered instead of saved and restored
+    asm volatile(
+        "s_mov_b32 m0, %0\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %1, %2, %3 offen lds"
+        :
+        : "s"(dst), "v"(voff), "s"(rsrc), "s"(soff)
+        : "memory", "m0");
+}
+
+#ifdef XVEC_DIAG
+// Diagnostic build only (make DIAG=1): s_memtime stamps of one wave per group, summed per segment kind.
+// slot = 16 * group + kind; kinds: 0-5 phase 0 (issue, wait, barrier, mfma, barrier, -), 6-11 phase 1
+__device__ unsigned long long g_pp16_diag[2 * 512 * 32];   // [pooling variant][block][group][kind]
+__device__ unsigned long long g_pp16_clk[8];               // block 0: s_memtime / s_memrealtime at entry and exit, per variant
+#define PP_STAMP(k_)                                                                               \
+    {                                                                                              \
+        SB();                                                                                      \
+        unsigned long long now_;                                                                   \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory");              \
+        dsum[k_] += now_ - dprev;                                                                  \
+        dprev = now_;                                                                              \
+        SB();                                                                                      \
+    }
+#else
+#define PP_STAMP(k_)
+#endif
+#ifdef XVEC_KNOCK
+// Timing-only knock-outs, compile time (-DXVEC_KNOCK=mask; results are garbage):
+//   bit 0: no DMA pieces in the K loop     bit 1: no LDS fragment reads (fragments stay zero)
+//   bit 2: no epilogue (stores / pooling)
+#define PP_KNOCK_DMA ((XVEC_KNOCK & 1) != 0)
+#define PP_KNOCK_RD ((XVEC_KNOCK & 2) != 0)
+#define PP_KNOCK_EPI ((XVEC_KNOCK & 4) != 0)
+#define PP_KNOCK_RDW ((XVEC_KNOCK & 8) != 0)     // bit 3: no W fragment reads only
+#define PP_KNOCK_RDA ((XVEC_KNOCK & 16) != 0)    // bit 4: no A fragment reads only
+#else
+#define PP_KNOCK_RDW false
+#define PP_KNOCK_RDA false
+#define PP_KNOCK_DMA false
+#define PP_KNOCK_RD false
+#define PP_KNOCK_EPI false
+#endif
+// lgkmcnt(0) as the BUILTIN (0xC07F = lgkmcnt 0, vmcnt / expcnt untouched): hipcc's wait-count pass sees it and
+// knows every earlier LDS read is back.  As inline asm it did not, and put lgkmcnt(3..0) waits for
+// fragments read a segment earlier in front of the MFMAs -- behind the freshly issued prefetch reads,
+// which serialised those reads with the MFMAs they were meant to hide under.
+#define PP_WAIT_LGKM()                          \
+    {                                           \
+        SB();                                   \
+        __builtin_amdgcn_s_waitcnt(0xC07F);     \
+        SB();                                   \
+    }
+#define PP_WAIT_VM(n_) asm volatile("s_waitcnt vmcnt(" #n_ ")" ::: "memory")
+// counted wait whose count is only known at run time (it depends on the next tile's height): one of the few
+// values the request schedule can produce; anything else waits for everything (stricter, never wrong)
+#define PP_WAIT_VM_RT(n_)                                        \
+    {                                                            \
+        const int nn_ = (n_);                                    \
+        if (nn_ == 10) { PP_WAIT_VM(10); }                       \
+        else if (nn_ == 9) { PP_WAIT_VM(9); }                    \
+        else if (nn_ == 8) { PP_WAIT_VM(8); }                    \
+        else if (nn_ == 7) { PP_WAIT_VM(7); }                    \
+        else if (nn_ == 6) { PP_WAIT_VM(6); }                    \
+        else if (nn_ == 2) { PP_WAIT_VM(2); }                    \
+        else if (nn_ == 1) { PP_WAIT_VM(1); }                    \
+        else { PP_WAIT_VM(0); }                                  \
+    }
+#define PP_BARRIER() \
+    {                \
+        SB();        \
+        __builtin_amdgcn_s_barrier(); \
+        SB();        \
+    }
+
+// Tile = `mr` accumulator rows per group (rows m0 .. m0 + 64*mr), of which rows below `valid_end`
+// belong to this block.
+struct Tile {
+    int64_t m0;
+    int64_t valid_end;
+    int mr;
+};
+
+// activation source of one tile: descriptor at its first row + this lane's byte offsets of the wave's A piece of
+// acc rows 0..3
+struct Rows {
+    i32x4 xrsrc;
+    int av0, av1, av2, av3;
+};
+
+struct Stream {
+    i32x4 wrsrc;
+    Rows cur;                   // tile the requests are for
+    int wv0;                    // and of its first W piece; the others are 64 channel rows (w64 bytes, scalar) apart
+    int w64;
+    unsigned lds_a, lds_w;      // LDS byte address (buffer 0) of this wave's A piece of acc row 0 / its first W piece
+    int u_tile;                 // utterance holding the stream tile's first row, and where the next one starts
+    int64_t off_next;
+};
+
+// per-lane source offsets of the wave's A pieces for the tile at row t.m0 (see set_tile_rows_impl in
+// tdnn_layer.hip: compact output row p of utterance u reads input rows p + u*span; the utterance
+// boundaries inside the tile are walked with block-uniform values, each lane counts the ones its
+// rows have passed)
+// (this lane's row within its group's acc row 0 and the swizzled 16-byte chunk it fetches are recomputed from the lane
+// id here, once per tile: held in registers across the K loop they were the three registers over the budget)
+template <bool RAGGED>
+__device__ __forceinline__ void set_rows(const TdnnArgs& a, const Tile& t, int grp, int wc, Stream& st, Rows& out) {
+    int lane_;            // volatile asm: as a builtin the compiler hoists it out of the tile loop and keeps it, again
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_));
+    const int row_in_group = wc * 8 + (lane_ >> 3);
+    const int a_chunk = ((lane_ & 7) ^ ((row_in_group >> 1) & 7)) * 16;
+    const int n_last = a.out_map.n_utts - 1;
+    const int64_t t_out = a.out_map.fixed_T - a.out_map.cum;
+    auto next_off = [&](int u) -> int64_t {
+        if (RAGGED) return sload_i64(a.out_map.offsets + __builtin_amdgcn_readfirstlane(u + 1)) - (int64_t)(u + 1) * a.out_map.cum;
+        return (int64_t)(u + 1) * t_out;
+    };
+    while (t.m0 >= st.off_next && st.u_tile < n_last) {
+        st.u_tile = __builtin_amdgcn_readfirstlane(st.u_tile + 1);
+        st.off_next = next_off(st.u_tile);
+    }
+    const int rl = grp * 32 * t.mr + row_in_group;     // row of this lane's acc-row-0 piece, relative to m0
+    const int64_t p = t.m0 + rl;
+    int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+    int u = st.u_tile;
+    int64_t nxt = st.off_next;
+    const int64_t t_end = t.m0 + 64 * t.mr;
+    while (nxt < t_end && u < n_last) {
+        c0 += (p >= nxt) ? 1 : 0;
+        c1 += (p + 32 >= nxt) ? 1 : 0;
+        c2 += (p + 64 >= nxt) ? 1 : 0;
+        c3 += (p + 96 >= nxt) ? 1 : 0;
+        u = __builtin_amdgcn_readfirstlane(u + 1);
+        nxt = next_off(u);
+    }
+    const int rb = a.ldx * 2;
+    const int base = rl * rb + a_chunk;
+    out.av0 = base + (st.u_tile + c0) * a.span * rb;
+    out.av1 = base + 32 * rb + (st.u_tile + c1) * a.span * rb;
+    out.av2 = base + 64 * rb + (st.u_tile + c2) * a.span * rb;
+    out.av3 = base + 96 * rb + (st.u_tile + c3) * a.span * rb;
+    out.xrsrc = make_srd(static_cast<const char*>(a.X) + t.m0 * (int64_t)a.ldx * 2);
+}
+
+__device__ __forceinline__ void set_rows(const TdnnArgs& a, const Tile& t, int grp, int wc, Stream& st, Rows& out) {
+    if (a.out_map.offsets == nullptr) set_rows<false>(a, t, grp, wc, st, out);
+    else set_rows<true>(a, t, grp, wc, st, out);
+}
+
+// Scalar source offset of the activation K-tiles, stepped one K-tile at a time (taps innermost:
+// tap 0, 1, .., then the next 64-channel block): no division in the loop.
+struct KPos {
+    int tap, so;
+};
+__device__ __forceinline__ void kstep(const TdnnArgs& a, KPos& k) {
+    const int tapstep = a.tap_rows * a.ldx * 2;
+    if (k.tap + 1 < a.n_taps) {
+        k.tap += 1;
+        k.so += tapstep;
+    } else {
+        k.so += 128 - k.tap * tapstep;
+        k.tap = 0;
+    }
+}
+
+// --- DMA piece groups of one wave (buffer b_ = parity of the K-tile) -------------------------
+// W: the wave's four pieces (channel rows 8*(wave + 8t) ..+7); A01 / A23: its piece of acc rows 0,1 / 2,(3)
+#define PP_ISSUE_W(b_, q_)                                                          \
+    {                                                                               \
+        const int so_ = (q_) * kWBytes;              /* K-tile major weights: 32 KiB per K-tile */ \
+        dma16(st.wrsrc, st.lds_w + (b_) * kBufBytes, st.wv0, so_);                  \
+        dma16(st.wrsrc, st.lds_w + (b_) * kBufBytes + 8 * 1024, st.wv0, so_ + st.w64);       \
+        dma16(st.wrsrc, st.lds_w + (b_) * kBufBytes + 16 * 1024, st.wv0, so_ + 2 * st.w64);  \
+        dma16(st.wrsrc, st.lds_w + (b_) * kBufBytes + 24 * 1024, st.wv0, so_ + 3 * st.w64);  \
+    }
+#define PP_ISSUE_A01(b_, so_)                                                       \
+    {                                                                               \
+        dma16(st.cur.xrsrc, st.lds_a + (b_) * kBufBytes, st.cur.av0, so_);                  \
+        dma16(st.cur.xrsrc, st.lds_a + (b_) * kBufBytes + kAccRowB, st.cur.av1, so_);       \
+    }
+#define PP_ISSUE_A23(MR_, b_, so_)                                                  \
+    {                                                                               \
+        if ((MR_) > 2) dma16(st.cur.xrsrc, st.lds_a + (b_) * kBufBytes + 2 * kAccRowB, st.cur.av2, so_);   \
+        if ((MR_) > 3) dma16(st.cur.xrsrc, st.lds_a + (b_) * kBufBytes + 3 * kAccRowB, st.cur.av3, so_); \
+    }
+
+// first K-tiles of a tile: part 1 = all of K-tile 0; part 2 = all of K-tile 1, in the K loop's request order
+// (acc rows 0,1, then W, then acc rows 2,3), which keeps the loop's counted waits uniform from the first K-tile
+template <bool POOL>
+__device__ __forceinline__ void issue_head1(const TdnnArgs& a, const Stream& st, int mr) {
+    PP_ISSUE_W(0, 0)
+    PP_ISSUE_A01(0, 0)
+    PP_ISSUE_A23(mr, 0, 0)
+}
+template <bool POOL>
+__device__ __forceinline__ void issue_head2(const TdnnArgs& a, const Stream& st, int mr) {
+    KPos k1 = {0, 0};
+    kstep(a, k1);
+    PP_ISSUE_A01(1, k1.so)
+    PP_ISSUE_W(1, 1)
+    PP_ISSUE_A23(mr, 1, k1.so)
+}
+
+struct Lane {
+    int q, r;        // lane quad (l >> 4): k chunk of a fragment, frames 4q..4q+3 of an accumulator; r = l & 15
+    int rd;          // r*128: row part of every fragment read
+    int k0, k1;      // swizzled byte offset of this lane's 16-byte chunk for k-steps 0, 1
+    unsigned a_rd;   // LDS byte offset (buffer 0) of this wave's group's acc row 0, + rd
+    unsigned w_rd;   // LDS byte offset (buffer 0) of this wave's channel column 0, + rd
+    int wave, grp, wc;
+};
+
+#define PP_RD(dst_, off_) if constexpr (!PP_KNOCK_RD) dst_ = *reinterpret_cast<const float4*>(smem + (off_));
+#define PP_RDW(dst_, off_) if constexpr (!PP_KNOCK_RDW) PP_RD(dst_, off_)
+constexpr int kBlk16 = 16 * kRowB;                // 16 rows of a 32-row block: 2 KiB
+// W fragments of K-tile in buffer b_: 4 channel blocks x 2 k-steps
+#define PP_READ_W(b_)                                                     \
+    {                                                                     \
+        const unsigned o_ = ln.w_rd + (b_) * kBufBytes;                   \
+        PP_RDW(wf0_0, o_ + ln.k0) PP_RDW(wf0_1, o_ + ln.k1)               \
+        PP_RDW(wf1_0, o_ + kBlk16 + ln.k0) PP_RDW(wf1_1, o_ + kBlk16 + ln.k1)          \
+        PP_RDW(wf2_0, o_ + 2 * kBlk16 + ln.k0) PP_RDW(wf2_1, o_ + 2 * kBlk16 + ln.k1)  \
+        PP_RDW(wf3_0, o_ + 3 * kBlk16 + ln.k0) PP_RDW(wf3_1, o_ + 3 * kBlk16 + ln.k1)  \
+    }
+// one MFMA: accumulator (acc row i_, frame block f_, channel block c_), k-step s_.  The activations are the MFMA A
+// operand: frames in the accumulator's registers (frame 4q + e), the channel on the lane.
+// Inline asm with the accumulator tied ("+v"): hipcc has no tied form of the 4-pass MFMAs (vdst may be any register),
+// its allocator let the 32 accumulators wander from MFMA to MFMA and ended 50 registers over the budget (spills that
+// wait on vmcnt(0) in the K loop).  What hipcc would otherwise look after, by hand: operands written by ds_read are
+// waited for by the compiler (it sees the asm's register uses); the same accumulator is never used by two MFMAs less than
+// four MFMAs apart; PP_MFMA_SETTLE() stands between the accumulators' initialisation / the K loop's last MFMA and
+// the vector instructions that write / read them.
+#define PP_MF(i_, f_, c_, s_)                                                                                       \
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc##i_##f_##c_) : "v"(__builtin_bit_cast(f32x4, af##i_##_##f_##s_)), "v"(__builtin_bit_cast(f32x4, wf##c_##_##s_)));
+#define PP_MFMA_SETTLE() asm volatile("s_nop 15\n\ts_nop 3" ::: "memory")
+// half a quad / a quad: (acc row, frame block, k-step) x channel blocks 0,1 / 2,3 / all four -- 2 x / 4 x 16 cycles
+#define PP_H0(i_, f_, s_) PP_MF(i_, f_, 0, s_) PP_MF(i_, f_, 1, s_) SB();
+#define PP_H1(i_, f_, s_) PP_MF(i_, f_, 2, s_) PP_MF(i_, f_, 3, s_) SB();
+#define PP_Q(i_, f_, s_) PP_H0(i_, f_, s_) PP_H1(i_, f_, s_)
+// one activation fragment read: acc row i_, frame block f_, k-step s_, from buffer b_.  A ds_read_b128 holds the
+// wave's issue for ~30 cycles (stamps, profiles/diag/pp_stamps.py), which is free exactly while MFMAs of this wave
+// are executing: ONE read behind every two MFMAs (32 cycles), never two in a row
+#define PP_RA(i_, f_, s_, b_) if constexpr (!PP_KNOCK_RDA) PP_RD(af##i_##_##f_##s_, ln.a_rd + (b_) * kBufBytes + (i_) * kAccRowB + (f_) * kBlk16 + ln.k##s_) SB();
+// half a quad followed by one read
+#define PP_H0R(i_, f_, s_, ri_, rf_, rs_, b_) PP_H0(i_, f_, s_) PP_RA(ri_, rf_, rs_, b_)
+#define PP_H1R(i_, f_, s_, ri_, rf_, rs_, b_) PP_H1(i_, f_, s_) PP_RA(ri_, rf_, rs_, b_)
+
+// One K-tile held in LDS buffer b_ (odd_ = its parity).  k2.so / wq = activation source offset and index of
+// the K-tile requested now, two K-tiles ahead; mr_req = height of the tile it belongs to.  The request stream
+// does not stop at the end of a tile: in a tile's last two K-tiles ("last") the requests are the NEXT tile's
+// K-tiles 0 and 1 (the stream state was switched to that tile just before), so a tile starts with its first
+// K-tiles in LDS and its first fragments in registers.  Only a block's last tile requests nothing there.
+//   load 0:  read the 8 W fragments; request acc rows 0,1 of K-tile q+2
+//   mfma 0:  MR=4: acc rows 0,1 (32 MFMAs of 16 cycles); MR=3: six of the twelve (row, frame block, k-step) quads
+//            of rows 0,1,2 (24); MR=2: k-step 0 (16) -- with the fragment reads of acc rows 2,(3) behind its first MFMAs
+//   load 1:  request W and acc rows 2,(3) of K-tile q+2
+//   mfma 1:  the other half -- with the fragment reads of acc rows 0,1 of K-tile q+1 behind its first MFMAs, each
+//            after the last MFMA that uses the register it overwrites
+// The two segments of a wave are equally long, so the SIMD partner's load segments have the same time to
+// hide in.  Activation fragments are never read in a load segment, and never two reads behind one MFMA.
+// Every segment ends with lgkmcnt(0) before its barrier (a slot may be refilled in any later segment).
+// Counted vmcnt at the end of a load segment (request order per wave: [rows 0,1] | [W, rows 2,3] | ...; m = this
+// tile's MR, m' = mr_req, equal except in the last two K-tiles):
+//   load 0 must have acc rows 2,3 of K-tile q  (requested three load segments ago): 2 + (m'+2) + 2 younger
+//   load 1 must have W of K-tile q+1 (two load segments ago) and rows 0,1 of q+1 (three): (m1-2) + 2 + (m'+2)
+//          younger, m1 = height of the tile K-tile q+1 belongs to
+// -- never a drain.  (The epilogue's stores sit in the same queue: the first waits of the next tile then
+// wait for a few entries more than they need to, which have long completed.)
+#define PP_KTILE(b_, odd_)                                                          \
+    {                                                                               \
+        SB();                                                                       \
+        PP_READ_W(b_)                                                               \
+        SB();                                                                       \
+        if (req && !PP_KNOCK_DMA) PP_ISSUE_A01(b_, k2.so)                           \
+        SB();                                                                       \
+        PP_WAIT_LGKM();                                                             \
+        PP_STAMP(0)                                                                 \
+        if (!last) { if (MR == 4) { PP_WAIT_VM(10); } else if (MR == 3) { PP_WAIT_VM(9); } else { PP_WAIT_VM(8); } } \
+        else if (!(odd_)) { PP_WAIT_VM_RT(req ? MR + 6 : MR + 4) }                  \
+        else { PP_WAIT_VM_RT(req ? mr_req + 6 : 0) }                                \
+        PP_STAMP(1)                                                                 \
+        PP_BARRIER()                                                                \
+        PP_STAMP(2)                                                                 \
+        __builtin_amdgcn_s_setprio(1);                                              \
+        if constexpr (MR == 2) {   /* k-step 0 of rows 0,1: nothing to read (no acc row 2) */ \
+            PP_Q(0, 0, 0) PP_Q(0, 1, 0) PP_Q(1, 0, 0) PP_Q(1, 1, 0)                 \
+        } else if constexpr (MR == 3) {                                             \
+            PP_H0R(0, 0, 0, 2, 0, 0, b_) PP_H1R(0, 0, 0, 2, 1, 0, b_)               \
+            PP_H0R(0, 1, 0, 2, 0, 1, b_) PP_H1R(0, 1, 0, 2, 1, 1, b_)               \
+            PP_Q(1, 0, 0) PP_Q(1, 1, 0) PP_Q(0, 0, 1) PP_Q(0, 1, 1)                 \
+        } else {                                                                    \
+            PP_H0R(0, 0, 0, 2, 0, 0, b_) PP_H1R(0, 0, 0, 2, 1, 0, b_)               \
+            PP_H0R(0, 1, 0, 2, 0, 1, b_) PP_H1R(0, 1, 0, 2, 1, 1, b_)               \
+            PP_H0R(1, 0, 0, 3, 0, 0, b_) PP_H1R(1, 0, 0, 3, 1, 0, b_)               \
+            PP_H0R(1, 1, 0, 3, 0, 1, b_) PP_H1R(1, 1, 0, 3, 1, 1, b_)               \
+            PP_Q(0, 0, 1) PP_Q(0, 1, 1) PP_Q(1, 0, 1) PP_Q(1, 1, 1)                 \
+        }                                                                           \
+        __builtin_amdgcn_s_setprio(0);                                              \
+        PP_WAIT_LGKM();                                                             \
+        PP_STAMP(3)                                                                 \
+        PP_BARRIER()                                                                \
+        PP_STAMP(4)                                                                 \
+        if (req && !PP_KNOCK_DMA) {                                                 \
+            PP_ISSUE_W(b_, wq)                                                      \
+            PP_ISSUE_A23(mr_req, b_, k2.so)                                         \
+        }                                                                           \
+        SB();                                                                       \
+        PP_STAMP(6)                                                                 \
+        if (!last) { if (MR == 4) { PP_WAIT_VM(10); } else if (MR == 3) { PP_WAIT_VM(8); } else { PP_WAIT_VM(6); } } \
+        else if (!(odd_)) { PP_WAIT_VM_RT(req ? MR + mr_req + 2 : MR - 2) }         \
+        else { PP_WAIT_VM_RT(req ? 2 * mr_req + 2 : 0) }                            \
+        PP_STAMP(7)                                                                 \
+        PP_BARRIER()                                                                \
+        PP_STAMP(8)                                                                 \
+        __builtin_amdgcn_s_setprio(1);                                              \
+        /* (after a block's last K-tile these reads fetch stale bytes that nobody uses: cheaper than a branch */ \
+        /*  around the MFMAs, which made hipcc keep two register assignments alive and spill) */ \
+        if constexpr (MR == 2) {   /* k-step 1; the k-step 0 fragments are free, the k-step 1 ones after their quad */ \
+            PP_H0R(0, 0, 1, 0, 0, 0, (b_) ^ 1) PP_H1R(0, 0, 1, 0, 1, 0, (b_) ^ 1)   \
+            PP_H0R(0, 1, 1, 1, 0, 0, (b_) ^ 1) PP_H1R(0, 1, 1, 1, 1, 0, (b_) ^ 1)   \
+            PP_H0R(1, 0, 1, 0, 0, 1, (b_) ^ 1) PP_H1R(1, 0, 1, 0, 1, 1, (b_) ^ 1)   \
+            PP_H0(1, 1, 1) PP_H1R(1, 1, 1, 1, 0, 1, (b_) ^ 1)                       \
+            PP_RA(1, 1, 1, (b_) ^ 1)                                                \
+        } else if constexpr (MR == 3) {   /* row 1 k-step 1, then row 2; row 0 is free, row 1 after its two quads */ \
+            PP_H0R(1, 0, 1, 0, 0, 0, (b_) ^ 1) PP_H1R(1, 0, 1, 0, 1, 0, (b_) ^ 1)   \
+            PP_H0R(1, 1, 1, 0, 0, 1, (b_) ^ 1) PP_H1R(1, 1, 1, 0, 1, 1, (b_) ^ 1)   \
+            PP_H0R(2, 0, 0, 1, 0, 0, (b_) ^ 1) PP_H1R(2, 0, 0, 1, 1, 0, (b_) ^ 1)   \
+            PP_H0R(2, 1, 0, 1, 0, 1, (b_) ^ 1) PP_H1R(2, 1, 0, 1, 1, 1, (b_) ^ 1)   \
+            PP_Q(2, 0, 1) PP_Q(2, 1, 1)                                             \
+        } else {                                                                    \
+            PP_H0R(2, 0, 0, 0, 0, 0, (b_) ^ 1) PP_H1R(2, 0, 0, 0, 1, 0, (b_) ^ 1)   \
+            PP_H0R(2, 1, 0, 0, 0, 1, (b_) ^ 1) PP_H1R(2, 1, 0, 0, 1, 1, (b_) ^ 1)   \
+            PP_H0R(3, 0, 0, 1, 0, 0, (b_) ^ 1) PP_H1R(3, 0, 0, 1, 1, 0, (b_) ^ 1)   \
+            PP_H0R(3, 1, 0, 1, 0, 1, (b_) ^ 1) PP_H1R(3, 1, 0, 1, 1, 1, (b_) ^ 1)   \
+            PP_Q(2, 0, 1) PP_Q(2, 1, 1) PP_Q(3, 0, 1) PP_Q(3, 1, 1)                 \
+        }                                                                           \
+        __builtin_amdgcn_s_setprio(0);                                              \
+        PP_WAIT_LGKM();                                                             \
+        PP_STAMP(9)                                                                 \
+        PP_BARRIER()                                                                \
+        PP_STAMP(10)                                                                \
+        kstep(a, k2);                                                               \
+        ++wq;                                                                       \
+    }
+
+// Fused statistics pooling for the pooling variant (main.py:59-63), frames in the accumulator registers and
+// the channel on the lane.  The epilogue runs in the open here (both waves of a SIMD are in it at the same
+// time, the matrix pipe idles), so it is as short as the arithmetic allows: per (32-frame group, utterance)
+// and channel the pivoted sums S1 = sum (r - K), S2 = sum (r - K)^2 of r = relu(z + bias) over the utterance's
+// frames in the group, K = the group's frame 0 (tdnn_common.h, pool_group_impl: why a pivot) -- one v_max, half a
+// v_pk_add for the pivot, half a v_pk_add and half a v_pk_fma per value.  Scale and shift of the folded BatchNorm
+// are applied by pool_finalize.
+// RAGGED is a template parameter and the utterance index is kept provably wave-uniform on purpose: with
+// a run-time "offsets ? load : multiply" hipcc emitted VECTOR loads of the offsets followed by
+// s_waitcnt vmcnt(0) -- on the fixed-length path too -- and every one of those waits drained the DMA
+// queue (the next tile's first K-tiles) in the middle of the epilogue.
+template <bool RAGGED>
+__device__ __forceinline__ int64_t first_row(const RowMap& m, int u) {
+    u = __builtin_amdgcn_readfirstlane(u);
+    if (RAGGED) return sload_i64(m.offsets + u) - (int64_t)u * m.cum;
+    return (int64_t)u * (m.fixed_T - m.cum);
+}
+// --- cross-lane helpers for the 16x16 accumulator layout (frames on the four lane quads q = l >> 4) --------------
+// {a summed over the two lane halves | b summed over the two lane halves}: v_permlane32_swap(a, b) returns
+// {a.lo | b.lo, a.hi | b.hi}; their sum holds a's total in the lower half and b's in the upper half
+__device__ __forceinline__ float swap32_add(float x, float y) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// the same one level down: v_permlane16_swap(a, b) returns {a.r0 | b.r0 | a.r2 | b.r2, a.r1 | b.r1 | a.r3 | b.r3} (rows of 16
+// lanes); the sum holds a.r0+a.r1 | b.r0+b.r1 | a.r2+a.r3 | b.r2+b.r3
+__device__ __forceinline__ float swap16_add(float x, float y) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// quad 0's x in every lane
+__device__ __forceinline__ float quad0(float x) {
+    const unsigned u = __float_as_uint(x);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);      // r[0] = {r0 | r0 | r2 | r2}
+    return lower_half(__uint_as_float(r[0]));
+}
+
+// One partial (tdnn_common.h: planes K | S1 | S2) of the lane's four adjacent columns col0..col0+3.  Every lane
+// quad holds the sums of ITS eight frames; the eight numbers (S1, S2 x 4 columns) are reduced over the quads as a
+// reduce-scatter -- four v_permlane32_swap + two v_permlane16_swap and six adds, after which quad 0 holds S1 of
+// columns 0,1, quad 2 S1 of columns 2,3, quad 1 S2 of columns 0,1 and quad 3 S2 of columns 2,3 -- and ONE 8-byte
+// store writes 256 contiguous bytes of the S1 plane and 256 of the S2 plane; quad 0 writes the pivots (16 bytes
+// per lane, 256 contiguous bytes of the K plane).
+__device__ __forceinline__ void store_quads(__amdgpu_buffer_rsrc_t prs, int ld, int64_t slot, int q, int col0, const f32x4& k,
+                                            const f32x4& s1, const f32x4& s2) {
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const float y0 = swap32_add(s1[0], s1[2]), y1 = swap32_add(s2[0], s2[2]);
+    const float y2 = swap32_add(s1[1], s1[3]), y3 = swap32_add(s2[1], s2[3]);
+    const float z0 = swap16_add(y0, y1), z1 = swap16_add(y2, y3);
+    const int soff = (int)(slot * kPoolPlanes * ld) * 4;
+    const u32x2 v = {__float_as_uint(z0), __float_as_uint(z1)};
+    __builtin_amdgcn_raw_buffer_store_b64(v, prs, (col0 + (q >> 1) * 2 + (1 + (q & 1)) * ld) * 4, soff, 0);
+    if (q == 0) {
+        const u32x4 kv = {__float_as_uint(k[0]), __float_as_uint(k[1]), __float_as_uint(k[2]), __float_as_uint(k[3])};
+        __builtin_amdgcn_raw_buffer_store_b128(kv, prs, col0 * 4, soff, 0);
+        asm volatile("s_nop 1" ::"v"(kv));       // the 128-bit-store data hazard (tdnn_common.h, store_acc)
+    }
+}
+
+// v{f}{c}: the accumulator of frame block f (frames 16 f + 4 q + e) and channel col0 + c, bias inside.
+template <bool RAGGED>
+__device__ __forceinline__ void pool_quads(const TdnnArgs& a, const f32x4& v00, const f32x4& v01, const f32x4& v02,
+                                           const f32x4& v03, const f32x4& v10, const f32x4& v11, const f32x4& v12,
+                                           const f32x4& v13, int64_t row_g, int q, int col0, PoolCur& pc) {
+    const RowMap& m = a.out_map;
+    while (pc.end <= row_g && pc.u < m.n_utts - 1) {
+        pc.u = __builtin_amdgcn_readfirstlane(pc.u + 1);
+        pc.end = first_row<RAGGED>(m, pc.u + 1);
+    }
+    const int64_t grp = row_g >> 5;
+    const int ld = a.ldy;
+    const __amdgpu_buffer_rsrc_t prs = make_rsrc(a.pool_part);
+    // pivots: the group's frame 0 (quad 0, frame block 0, register 0) of the lane's four channels (tdnn_common.h,
+    // pool_group_impl: why a pivot)
+    const f32x4 k = {quad0(fmaxf(v00[0], 0.f)), quad0(fmaxf(v01[0], 0.f)), quad0(fmaxf(v02[0], 0.f)), quad0(fmaxf(v03[0], 0.f))};
+    if (pc.end >= row_g + 32) {               // the whole group belongs to utterance pc.u
+        f32x4 s1, s2;
+        // two values per instruction where the ISA has one (v_pk_add_f32 / v_pk_fma_f32; the max has none)
+#define PQ_SUM(c_)                                                                                            \
+        {                                                                                                     \
+            const f32x2 kk = {k[c_], k[c_]};                                                                  \
+            const f32x2 d0 = f32x2{fmaxf(v0##c_[0], 0.f), fmaxf(v0##c_[1], 0.f)} - kk;                         \
+            const f32x2 d1 = f32x2{fmaxf(v0##c_[2], 0.f), fmaxf(v0##c_[3], 0.f)} - kk;                         \
+            const f32x2 d2 = f32x2{fmaxf(v1##c_[0], 0.f), fmaxf(v1##c_[1], 0.f)} - kk;                         \
+            const f32x2 d3 = f32x2{fmaxf(v1##c_[2], 0.f), fmaxf(v1##c_[3], 0.f)} - kk;                         \
+            const f32x2 p1 = (d0 + d1) + (d2 + d3);                                                           \
+            f32x2 p2 = d0 * d0;                                                                               \
+            p2 = __builtin_elementwise_fma(d1, d1, p2);                                                       \
+            p2 = __builtin_elementwise_fma(d2, d2, p2);                                                       \
+            p2 = __builtin_elementwise_fma(d3, d3, p2);                                                       \
+            s1[c_] = p1.x + p1.y;                                                                             \
+            s2[c_] = p2.x + p2.y;                                                                             \
+        }
+        PQ_SUM(0) PQ_SUM(1) PQ_SUM(2) PQ_SUM(3)
+#undef PQ_SUM
+        store_quads(prs, ld, grp + pc.u, q, col0, k, s1, s2);
+        return;
+    }
+    for (int u = pc.u; u < m.n_utts; u = __builtin_amdgcn_readfirstlane(u + 1)) {   // the group straddles utterances
+        const int64_t off = first_row<RAGGED>(m, u);
+        if (off >= row_g + 32) break;
+        const int64_t end = first_row<RAGGED>(m, u + 1);
+        const int64_t lo_r = off > row_g ? off : row_g;
+        const int64_t hi_r = end < row_g + 32 ? end : row_g + 32;
+        if (hi_r <= lo_r) continue;
+        const int lo_l = (int)(lo_r - row_g), hi_l = (int)(hi_r - row_g);
+        const unsigned below_hi = hi_l >= 32 ? 0xffffffffu : ((1u << hi_l) - 1u);
+        const unsigned lm = (below_hi & ~((1u << lo_l) - 1u)) >> (4 * q);   // this lane's frames: bits 16 f + e
+        f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+#define PQ_MASKED(f_, c_)                                                                                     \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                       \
+            const bool in = (lm >> (16 * f_ + e)) & 1u;          /* a SELECT: rows outside may hold anything */ \
+            const float d = in ? fmaxf(v##f_##c_[e], 0.f) - k[c_] : 0.f;                                       \
+            s1[c_] += d;                                                                                      \
+            s2[c_] = fmaf(d, d, s2[c_]);                                                                      \
+        }
+        PQ_MASKED(0, 0) PQ_MASKED(1, 0) PQ_MASKED(0, 1) PQ_MASKED(1, 1)
+        PQ_MASKED(0, 2) PQ_MASKED(1, 2) PQ_MASKED(0, 3) PQ_MASKED(1, 3)
+#undef PQ_MASKED
+        store_quads(prs, ld, grp + u, q, col0, k, s1, s2);
+    }
+}
+
+// One tile: K loop, request of the next tile's first K-tiles, epilogue.
+template <int MR, bool POOL>
+__device__ __forceinline__ void process_tile(const TdnnArgs& a, char* smem, Stream& st, const Lane& ln,
+                                             const Tile& t, const Tile& nxt, bool has_next, bool first, int n0, int nk,
+                                             PoolCur& pc) {
+    // source rows of the NEXT tile (its first K-tiles are requested during this tile's last two): worked out
+    // here, before the accumulators exist, and parked in four registers
+    Rows rows_next = st.cur;
+    if (has_next) set_rows(a, nxt, ln.grp, ln.wc, st, rows_next);
+    // the accumulators start at the bias of their lane's four channels (64*wc + 4r .. +3 of the block's column; the
+    // constants live in a 3-KiB LDS table: registers held across the K loop were what a third tile height cost)
+    const float* cst = reinterpret_cast<const float*>(smem + kConstOff) + ln.wc * 64 + 4 * ln.r;
+#define PP_ACCS(i_) acc##i_##00, acc##i_##01, acc##i_##02, acc##i_##03, acc##i_##10, acc##i_##11, acc##i_##12, acc##i_##13
+    f32x4 PP_ACCS(0), PP_ACCS(1), PP_ACCS(2), PP_ACCS(3);
+    {
+        const float4 bi = *reinterpret_cast<const float4*>(cst);
+#define PP_INIT(i_)                                                                                      \
+        acc##i_##00 = f32x4{bi.x, bi.x, bi.x, bi.x}; acc##i_##01 = f32x4{bi.y, bi.y, bi.y, bi.y};          \
+        acc##i_##02 = f32x4{bi.z, bi.z, bi.z, bi.z}; acc##i_##03 = f32x4{bi.w, bi.w, bi.w, bi.w};          \
+        acc##i_##10 = acc##i_##00; acc##i_##11 = acc##i_##01; acc##i_##12 = acc##i_##02; acc##i_##13 = acc##i_##03;
+        PP_INIT(0) PP_INIT(1) PP_INIT(2) PP_INIT(3)
+#undef PP_INIT
+    }
+    PP_MFMA_SETTLE();
+    float4 wf0_0, wf0_1, wf1_0, wf1_1, wf2_0, wf2_1, wf3_0, wf3_1;     // [channel block]_[k-step]
+    float4 af0_00, af0_01, af0_10, af0_11, af1_00, af1_01, af1_10, af1_11;   // acc rows 0,1: [frame block][k-step] (read during the previous mfma 1)
+    float4 af2_00, af2_01, af2_10, af2_11, af3_00, af3_01, af3_10, af3_11;   // acc rows 2,3 (read during mfma 0)
+#ifdef XVEC_DIAG
+    unsigned long long dsum[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long dprev, dstart;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dstart)::"memory");
+#endif
+
+#ifdef XVEC_KNOCK
+    if (PP_KNOCK_RD || PP_KNOCK_RDW || PP_KNOCK_RDA) {
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        wf0_0 = wf0_1 = wf1_0 = wf1_1 = wf2_0 = wf2_1 = wf3_0 = wf3_1 = z;
+        af0_00 = af0_01 = af0_10 = af0_11 = af1_00 = af1_01 = af1_10 = af1_11 = z;
+        af2_00 = af2_01 = af2_10 = af2_11 = af3_00 = af3_01 = af3_10 = af3_11 = z;
+    }
+#endif
+    // A block's first tile waits for its first K-tile (requested by the kernel prologue; its pieces are older
+    // than the MR+4 of K-tile 1); later tiles find it in LDS, confirmed by the previous tile's last K-tiles.
+    if (first) {
+        if (MR == 4) { PP_WAIT_VM(8); } else if (MR == 3) { PP_WAIT_VM(7); } else { PP_WAIT_VM(6); }
+        PP_BARRIER()
+    }
+    // acc rows 0,1 of K-tile 0: the only activation fragments read outside an MFMA segment (the previous tile's
+    // last MFMA segment fetched them too, but keeping them in registers across the epilogue costs it 32 VGPRs)
+    PP_RA(0, 0, 0, 0) PP_RA(0, 0, 1, 0) PP_RA(0, 1, 0, 0) PP_RA(0, 1, 1, 0)
+    PP_RA(1, 0, 0, 0) PP_RA(1, 0, 1, 0) PP_RA(1, 1, 0, 0) PP_RA(1, 1, 1, 0)
+    PP_WAIT_LGKM();
+    // Their slots are the first ones the loop refills (load 0 of K-tile 0 requests K-tile 2 into them), and the
+    // waves of a group leave the epilogue at different times: every wave must have read them before any wave
+    // may request.  (Deferring that one request instead costs a branch in the loop, and with it hipcc's
+    // register assignment: 160 spilled registers.)
+    PP_BARRIER()
+    if (ln.grp == 1) PP_BARRIER()          // ping-pong: the second group runs one barrier behind
+#ifdef XVEC_DIAG
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dprev)::"memory");
+    dsum[12] += dprev - dstart;            // head wait
+#endif
+    KPos k2 = {0, 0};                       // K-tile requested now (two ahead of the one computed), its W index,
+    kstep(a, k2);                           // the height of its tile, and whether there is anything to request
+    kstep(a, k2);
+    int wq = 2;
+    int mr_req = MR;
+    bool req = true;
+    for (int q = 0; q < nk; q += 2) {
+        const bool last = q + 2 >= nk;
+        if (last) {                         // from here on the requests are the next tile's K-tiles 0 and 1
+            req = has_next;                 // (a peeled copy of the last pair made hipcc spill ~250 registers)
+            if (has_next) {
+                st.cur = rows_next;
+                mr_req = nxt.mr;
+                k2.tap = 0;
+                k2.so = 0;
+                wq = 0;
+            }
+        }
+        PP_KTILE(0, false)
+        PP_KTILE(1, true)
+    }
+    if (ln.grp == 0) PP_BARRIER()
+    PP_MFMA_SETTLE();
+    PP_STAMP(13)                            // tail barrier
+    PP_STAMP(5)
+
+    const int64_t row0 = t.m0 + ln.grp * 32 * MR;
+#define PP_ACCV(i_) "v"(acc##i_##00), "v"(acc##i_##01), "v"(acc##i_##02), "v"(acc##i_##03), "v"(acc##i_##10), "v"(acc##i_##11), "v"(acc##i_##12), "v"(acc##i_##13)
+    if constexpr (PP_KNOCK_EPI) {
+        asm volatile("" ::PP_ACCV(0), PP_ACCV(1));
+        asm volatile("" ::PP_ACCV(2), PP_ACCV(3));
+    } else if constexpr (!POOL) {
+        // ReLU + folded BatchNorm (tdnn_layer.py:30-39).  The lane's four accumulators of a frame hold the ADJACENT
+        // channels 4r..4r+3 of the wave's 64-channel block (pack.hip, shape 16): two v_cvt_pk_bf16_f32 make the 8
+        // bytes that belong at column 4r, and one store instruction writes whole 128-byte row segments of four
+        // frames (lane quad q = frames 4q..4q+3 of a 16-frame block: register e of quad q is frame 4q + e).
+        // (64-bit stores: the data hazard behind 128-bit buffer stores, tdnn_common.h store_acc, does not apply.)
+        typedef float f32x2v __attribute__((ext_vector_type(2)));
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        const __amdgpu_buffer_rsrc_t yrsrc = make_rsrc(static_cast<char*>(a.Y) + (t.m0 * (int64_t)a.ldy + n0) * 2);
+        const int y_voff = (4 * ln.q * a.ldy + ln.wc * 64 + 4 * ln.r) * 2;
+        const float4 sc = *reinterpret_cast<const float4*>(cst + 256), sh = *reinterpret_cast<const float4*>(cst + 512);
+#define PP_STORE_F(i_, f_)                                                                             \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                               \
+                const float v0 = fmaf(fmaxf(acc##i_##f_##0[e], 0.f), sc.x, sh.x);                         \
+                const float v1 = fmaf(fmaxf(acc##i_##f_##1[e], 0.f), sc.y, sh.y);                         \
+                const float v2 = fmaf(fmaxf(acc##i_##f_##2[e], 0.f), sc.z, sh.z);                         \
+                const float v3 = fmaf(fmaxf(acc##i_##f_##3[e], 0.f), sc.w, sh.w);                         \
+                const u32x2 pk = {__builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{v0, v1}, bf16x2)), \
+                                  __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{v2, v3}, bf16x2))}; \
+                __builtin_amdgcn_raw_buffer_store_b64(pk, yrsrc, y_voff,                                  \
+                                                      (ln.grp * 32 * MR + 32 * i_ + 16 * f_ + e) * a.ldy * 2, 0); \
+            }
+#define PP_STORE(i_)                                                                                   \
+        if (MR > i_ && row0 + 32 * i_ < t.valid_end) { PP_STORE_F(i_, 0) PP_STORE_F(i_, 1) }
+        PP_STORE(0) PP_STORE(1) PP_STORE(2) PP_STORE(3)
+#undef PP_STORE
+#undef PP_STORE_F
+    } else {
+        const int col0 = n0 + ln.wc * 64 + 4 * ln.r;
+#define PP_POOL(RG_, i_)                                                                               \
+        if (MR > i_ && row0 + 32 * i_ < t.valid_end) {                                                    \
+            pool_quads<RG_>(a, acc##i_##00, acc##i_##01, acc##i_##02, acc##i_##03, acc##i_##10, acc##i_##11, acc##i_##12, \
+                            acc##i_##13, row0 + 32 * i_, ln.q, col0, pc);                                 \
+        }
+        if (a.out_map.offsets == nullptr) {
+            PP_POOL(false, 0) PP_POOL(false, 1) PP_POOL(false, 2) PP_POOL(false, 3)
+        } else {
+            PP_POOL(true, 0) PP_POOL(true, 1) PP_POOL(true, 2) PP_POOL(true, 3)
+        }
+#undef PP_POOL
+    }
+#undef PP_ACCV
+#undef PP_ACCS
+#ifdef XVEC_DIAG
+    {
+        unsigned long long dend;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dend)::"memory");
+        dsum[11] += dend - dprev;          // epilogue + second K-tile of the next tile
+        dsum[14] += 1;
+        dsum[15] += (unsigned long long)MR;
+        if ((ln.wave & 3) == 0 && ln.r == 0 && ln.q == 0 && blockIdx.x < 512) {
+            _Pragma("unroll") for (int k = 0; k < 16; ++k) g_pp16_diag[(POOL ? 512 * 32 : 0) + blockIdx.x * 32 + ln.grp * 16 + k] += dsum[k];
+        }
+    }
+#endif
+}
+
+template <bool POOL>
+__global__ __launch_bounds__(kThreads, 2) void tdnn_pp_kernel(const TdnnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int jcol = lid % a.n_tiles;                   // 256-channel column
+    const int prange = lid / a.n_tiles;
+    const int64_t u_begin = a.groups_total * (int64_t)prange / a.blocks_per_col;     // 64-frame units
+    const int64_t u_end = a.groups_total * (int64_t)(prange + 1) / a.blocks_per_col;
+    const int n0 = jcol * 256;
+    const int nk = a.n_taps * a.cpt;                    // K-tiles of 64 (even)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+#ifdef XVEC_DIAG
+    if (blockIdx.x == 0 && tid == 0) {
+        g_pp16_clk[(POOL ? 4 : 0) + 0] = __builtin_amdgcn_s_memtime();
+        g_pp16_clk[(POOL ? 4 : 0) + 1] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
+    Lane ln;
+    ln.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    ln.grp = ln.wave >> 2;
+    ln.wc = ln.wave & 3;
+    ln.q = lane >> 4;
+    ln.r = lane & 15;
+    ln.rd = ln.r * kRowB;
+    {
+        // fragment of k-step s: k = 32 s + 8 q ..+7 = 16-byte chunk 4 s + q of the row's 128-byte slab, at the
+        // swizzled position chunk ^ ((row >> 1) & 7); row = 16 fb + r, so the swizzle does not depend on fb
+        const int sw = (ln.r >> 1) & 7;
+        ln.k0 = ((0 + ln.q) ^ sw) << 4;
+        ln.k1 = ((4 + ln.q) ^ sw) << 4;
+    }
+    ln.a_rd = ln.grp * 4 * kAccRowB + ln.rd;
+    ln.w_rd = kABytes + ln.wc * 2 * kAccRowB + ln.rd;
+
+    // per-channel constants of the block's column -> LDS
+    if (tid < 192) {
+        const int arr = tid >> 6, c4 = (tid & 63) * 4;
+        const float* src = arr == 0 ? a.bias : arr == 1 ? a.scale : a.shift;
+        *reinterpret_cast<float4*>(smem + kConstOff + arr * 1024 + c4 * 4) = *reinterpret_cast<const float4*>(src + n0 + c4);
+    }
+
+    // DMA map of this wave: piece row = lane >> 3 (8 rows per piece), LDS position lane & 7 holds the
+    // source chunk (lane & 7) ^ swizzle(row), swizzle = (row >> 1) & 7 of the row's index in its 32-row block
+    Stream st;
+    const int prow = lane >> 3, ppos = lane & 7;
+    {
+        // (A pieces: row ln.wc * 8 + prow of the 32-frame acc row, chunk ppos ^ swizzle: set_rows)
+        st.lds_a = (unsigned)(unsigned long long)(lds_ptr)(smem) + ln.grp * 4 * kAccRowB + ln.wc * 1024;
+        const int wr = ln.wave * 8 + prow;                                // W: channel row of piece t = wr + 64*t
+        const int w_chunk = (ppos ^ ((wr >> 1) & 7)) * 16;                // ((wr + 64t) >> 1) & 7 is the same for every t
+        st.lds_w = (unsigned)(unsigned long long)(lds_ptr)(smem) + kABytes + ln.wave * 1024;
+        st.wv0 = wr * kRowB + w_chunk;                                    // K-tile major: rows 128 B apart
+        st.w64 = 64 * kRowB;
+        st.wrsrc = make_srd(static_cast<const char*>(a.W) + (int64_t)jcol * nk * kWBytes);
+        st.cur.av0 = st.cur.av1 = st.cur.av2 = st.cur.av3 = 0;
+        st.u_tile = __builtin_amdgcn_readfirstlane(utt_of_row(a.out_map, u_begin * 64));
+        st.off_next = row_off(a.out_map, st.u_tile + 1);
+        st.cur.xrsrc = st.wrsrc;
+        PoolCur pc;
+        pc.u = 0;
+        pc.end = 0;
+
+        // tiles of this block: n units cut into ceil(n/4) tiles of 4, 3 or 2 units, as equal as possible (5 = 3 + 2:
+        // without the 2-unit tile a batch of 128 utterances ran slower than one of 96); n = 1: one 2-unit tile whose
+        // second unit lies past the range and is masked
+        const int n = (int)(u_end - u_begin);
+        if (n <= 0) return;
+        int nt = (n + 3) / 4;
+        int base = n / nt, extra = n % nt;
+        constexpr int kMinMr = 2;
+        if (base < kMinMr) { base = kMinMr; extra = 0; nt = (n + kMinMr - 1) / kMinMr; }
+        const int64_t range_end = u_end * 64;
+
+        auto tile_at = [&](int idx, int64_t m0) {
+            Tile t;
+            t.m0 = m0;
+            t.mr = idx < extra ? base + 1 : base;
+            t.valid_end = range_end;
+            return t;
+        };
+        Tile cur = tile_at(0, u_begin * 64);
+        if (POOL) pc = pool_cursor(a, cur.m0 + ln.grp * 32 * cur.mr);
+        set_rows(a, cur, ln.grp, ln.wc, st, st.cur);
+        __syncthreads();                                   // constants visible; nobody reads LDS buffers yet
+        issue_head1<POOL>(a, st, cur.mr);
+        issue_head2<POOL>(a, st, cur.mr);
+        for (int idx = 0; idx < nt; ++idx) {
+            const bool has_next = idx + 1 < nt;
+            Tile nxt = cur;
+            if (has_next) nxt = tile_at(idx + 1, cur.m0 + 64 * cur.mr);
+            if (cur.mr == 4)
+                process_tile<4, POOL>(a, smem, st, ln, cur, nxt, has_next, idx == 0, n0, nk, pc);
+            else if (cur.mr == 3)
+                process_tile<3, POOL>(a, smem, st, ln, cur, nxt, has_next, idx == 0, n0, nk, pc);
+            else
+                process_tile<2, POOL>(a, smem, st, ln, cur, nxt, has_next, idx == 0, n0, nk, pc);
+            cur = nxt;
+        }
+#ifdef XVEC_DIAG
+        if (blockIdx.x == 0 && tid == 0) {
+            g_pp16_clk[(POOL ? 4 : 0) + 2] = __builtin_amdgcn_s_memtime();
+            g_pp16_clk[(POOL ? 4 : 0) + 3] = __builtin_amdgcn_s_memrealtime();
+        }
+#endif
+    }
+}
+
+}  // namespace pp16
+
+#ifdef XVEC_DIAG
+extern "C" int xvec_pp16_clk_read(unsigned long long* host) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(pp16::g_pp16_clk), 8 * 8);
+}
+extern "C" int xvec_pp16_diag_read(unsigned long long* host, int n_words, int reset) {
+    hipError_t e = hipMemcpyFromSymbol(host, HIP_SYMBOL(pp16::g_pp16_diag), (size_t)n_words * 8);
+    if (e == hipSuccess && reset) e = hipMemset(nullptr, 0, 0);
+    if (reset) {
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(pp16::g_pp16_diag)) == hipSuccess) (void)hipMemset(p, 0, sizeof(unsigned long long) * 2 * 512 * 32);
+    }
+    return (int)e;
+}
+#endif
+
+hipError_t launch_tdnn_pp16(const TdnnArgs& a, bool pool, hipStream_t s) {
+    if (a.groups_total <= 0 || a.blocks_per_col <= 0 || a.blocks_per_col > a.groups_total || (a.cpt & 1) ||
+        a.n_tiles <= 0)
+        return hipErrorInvalidValue;
+    const int grid = a.blocks_per_col * a.n_tiles;
+    if (pool) {
+        static LdsOptIn opt;
+        if (hipError_t e = opt.ensure(reinterpret_cast<const void*>(pp16::tdnn_pp_kernel<true>), pp16::kLdsBytes); e != hipSuccess)
+            return e;
+        pp16::tdnn_pp_kernel<true><<<dim3(grid), dim3(pp16::kThreads), pp16::kLdsBytes, s>>>(a);
+    } else {
+        static LdsOptIn opt;
+        if (hipError_t e = opt.ensure(reinterpret_cast<const void*>(pp16::tdnn_pp_kernel<false>), pp16::kLdsBytes); e != hipSuccess)
+            return e;
+        pp16::tdnn_pp_kernel<false><<<dim3(grid), dim3(pp16::kThreads), pp16::kLdsBytes, s>>>(a);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace xvec

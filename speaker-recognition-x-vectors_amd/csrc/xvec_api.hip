@@ -68,6 +68,7 @@ struct xvec_handle {
     void* Wp16[XVEC_NUM_TDNN];         // bf16, fragment-major
     void* Wr16[XVEC_NUM_TDNN];         // bf16, row-major [n_pad][k_pad] (tdnn_pp.hip: both operands reach LDS by DMA)
     bool use_pp;                       // large-batch bf16 mapping enabled (XVEC_PP=0 disables it: A/B runs)
+    int pp_shape;                      // its MFMA shape: 16 (v_mfma_f32_16x16x32_bf16, tdnn_pp16.hip) or 32 (XVEC_PP_SHAPE=32: tdnn_pp.hip)
     void* Wp48[XVEC_NUM_TDNN];         // bf16x3: per chunk W_hi then W_lo fragments (2x the size), fragment-major
     float* Wp[XVEC_NUM_TDNN];
     float* vec[XVEC_NUM_TDNN];         // bias | scale | shift, n_pad each
@@ -249,7 +250,8 @@ int run_tdnn(xvec_handle* h, int layer, TdnnVariant v, const void* X, int ldx, i
             a.blocks_per_col = bpc;
             a.groups_total = units;
             a.pair_period = 0;
-            HIP_TRY(launch_tdnn_pp(a, v == TdnnVariant::kBf16Pool, s));
+            if (h->pp_shape == 16) HIP_TRY(launch_tdnn_pp16(a, v == TdnnVariant::kBf16Pool, s));
+            else HIP_TRY(launch_tdnn_pp(a, v == TdnnVariant::kBf16Pool, s));
             h->last_kernel[layer] = XVEC_KERNEL_PP;
             return XVEC_OK;
         }
@@ -442,6 +444,8 @@ int xvec_create(const xvec_cfg* cfg, xvec_handle** out) {
         if (h->blocks_per_cu < 1) h->blocks_per_cu = 1;
         const char* p = getenv("XVEC_PP");
         h->use_pp = !(p && atoi(p) == 0);
+        const char* sh = getenv("XVEC_PP_SHAPE");
+        h->pp_shape = (sh && atoi(sh) == 32) ? 32 : 16;
     }
     h->cin_pad = round_up(cfg->input_size, 4);
     fill_geometry(h, h->geo, 2 * kBK);
@@ -523,7 +527,7 @@ int xvec_load_tdnn(xvec_handle* h, int layer, const float* weight, const float* 
                              h->vec[layer], h->vec[layer] + g.n_pad, h->vec[layer] + 2 * g.n_pad,
                              static_cast<hipStream_t>(stream)));
     HIP_TRY(launch_pack_tdnn_bf16(weight, h->geo16[layer], h->Wp16[layer], static_cast<hipStream_t>(stream)));
-    HIP_TRY(launch_pack_tdnn_rows_bf16(weight, h->geo16[layer], h->Wr16[layer], static_cast<hipStream_t>(stream)));
+    HIP_TRY(launch_pack_tdnn_rows_bf16(weight, h->geo16[layer], h->Wr16[layer], h->pp_shape, static_cast<hipStream_t>(stream)));
     {
         TdnnGeom g3 = h->geo16[layer];
         g3.terms = 2;

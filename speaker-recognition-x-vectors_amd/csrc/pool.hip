@@ -162,10 +162,56 @@ __global__ __launch_bounds__(256) void pool_finalize_kernel(const PoolFinalizeAr
     o[a.C + ch] = (n > 1.0) ? (float)((sc < 0.0 ? -sc : sc) * sqrt(var_r)) : __builtin_nanf("");
 }
 
+// The same merge for the segment partials of tdnn_pp16.hip: one partial per (block b of the column, utterance u, frames
+// half g) at slot 2 (b + u) + g, n frames behind it in cnt[slot] (possibly none), for every block whose row range
+// overlaps the utterance.
+__global__ __launch_bounds__(256) void pool_finalize_seg_kernel(const PoolFinalizeArgs a) {
+    const int u = blockIdx.y;
+    const int ch = blockIdx.x * 256 + threadIdx.x;
+    if (ch >= a.C) return;
+    const int64_t off = row_off(a.map, u), end = row_off(a.map, u + 1);   // pooled rows are [off, end)
+    // block holding unit x: the largest b with floor(units_total * b / blocks_per_col) <= x
+    const int64_t U = a.units_total, P = a.blocks_per_col;
+    const int b_lo = (int)((((off >> 6) + 1) * P - 1) / U), b_hi = (int)(((((end - 1) >> 6) + 1) * P - 1) / U);
+    double s1 = 0.0, s2 = 0.0, k0 = 0.0;
+    bool have = false;
+    for (int b = b_lo; b <= b_hi; ++b) {
+        int n[2];
+        float pk[2], p1[2], p2[2];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int64_t slot = 2 * ((int64_t)b + u) + g;
+            const float* p = a.part + slot * (int64_t)(3 * a.n_pad);
+            n[g] = a.cnt[slot];
+            pk[g] = p[ch];
+            p1[g] = p[a.n_pad + ch];
+            p2[g] = p[2 * a.n_pad + ch];
+        }
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            if (n[g] > 0) {
+                if (!have) { k0 = (double)pk[g]; have = true; }
+                const double ng = (double)n[g], d = (double)pk[g] - k0, t1 = (double)p1[g];
+                s1 += t1 + ng * d;
+                s2 += (double)p2[g] + d * (2.0 * t1 + ng * d);
+            }
+        }
+    }
+    const double n = (double)(end - off);
+    const double sc = (double)a.scale[ch], sh = (double)a.shift[ch];
+    const double mean_d = s1 / n;
+    double var_r = (s2 - s1 * mean_d) / (n - 1.0);
+    var_r = var_r > 0.0 ? var_r : 0.0;
+    float* o = a.out + (int64_t)u * 2 * a.C;
+    o[ch] = (float)(sh + sc * (k0 + mean_d));
+    o[a.C + ch] = (n > 1.0) ? (float)((sc < 0.0 ? -sc : sc) * sqrt(var_r)) : __builtin_nanf("");
+}
+
 hipError_t launch_pool_finalize(const PoolFinalizeArgs& a, hipStream_t s) {
     if (a.map.n_utts <= 0) return hipSuccess;
     dim3 grid((a.C + 255) / 256, a.map.n_utts);
-    pool_finalize_kernel<<<grid, 256, 0, s>>>(a);
+    if (a.cnt) pool_finalize_seg_kernel<<<grid, 256, 0, s>>>(a);
+    else pool_finalize_kernel<<<grid, 256, 0, s>>>(a);
     return hipGetLastError();
 }
 

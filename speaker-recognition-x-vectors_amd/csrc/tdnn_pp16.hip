@@ -52,10 +52,13 @@ constexpr int kRowB = 128;                        // one K-tile slab of one row:
 constexpr int kAccRowB = 32 * kRowB;              // 32 frames: 4 KiB = 4 DMA pieces
 constexpr int kABytes = 2 * 4 * kAccRowB;         // [group][acc row][32 frames]: 32 KiB
 constexpr int kWBytes = 256 * kRowB;              // 256 channels: 32 KiB = 32 DMA pieces
-constexpr int kBufBytes = kABytes + kWBytes;      // 64 KiB
-constexpr int kConstOff = 2 * kBufBytes;
+constexpr int kBufBytes = kABytes + kWBytes;      // 64 KiB per K-tile buffer (K-tile parity); LDS image: A0 | A1 | W0 | W1, so
+constexpr int kWOff = 2 * kABytes;                // that BOTH buffers of an operand lie within the 64 KiB reach of a ds_read's
+constexpr int kConstOff = 2 * kBufBytes;          // offset field from one base register (A0 | W0 | A1 | W1 cost four more)
 constexpr int kConstBytes = 3 * 256 * 4;          // bias | scale | shift of the block's 256 channels, natural order
-constexpr int kLdsBytes = kConstOff + kConstBytes;
+constexpr int kParkOff = kConstOff + kConstBytes; // pooling variant: 48 bytes per thread (pivot | S1 | S2 of the lane's four
+constexpr int kParkBytes = 512 * 48;              // channels), the running sums of a wave's current utterance between two epilogues
+constexpr int kLdsBytes = kParkOff + kParkBytes;
 constexpr int kThreads = 512;
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -76,6 +79,20 @@ __device__ __forceinline__ i32x4 make_srd(const void* p) {
 // next ds_read; this way the pieces are invisible to its bookkeeping and are waited for by hand
 // (counted vmcnt before the barrier that publishes them).
 __device__ __forceinline__ void dma16(const i32x4& rsrc, unsigned dst, int voff, int soff) {
+#ifdef XVEC_DIAG   // diagnostic build (more scalar pressure): keep a folded constant out of soffset and the descriptor in SGPRs
+    asm volatile("s_mov_b32 %0, %1" : "=s"(soff) : "s"(soff));
+    i32x4 rs_;
+    rs_.x = __builtin_amdgcn_readfirstlane(rsrc.x); rs_.y = __builtin_amdgcn_readfirstlane(rsrc.y);
+    rs_.z = __builtin_amdgcn_readfirstlane(rsrc.z); rs_.w = __builtin_amdgcn_readfirstlane(rsrc.w);
+    asm volatile(
+        "s_mov_b32 m0, %0\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %1, %2, %3 offen lds"
+        :
+        : "s"(dst), "v"(voff), "s"(rs_), "s"(soff)
+        : "memory", "m0");
+    return;
+#endif
     // dst / soff / rsrc are SALU results (no VALU-written SGPR feeds the load: no wait states needed
     // beyond the one after the M0 write); M0 is declared clobbered instead of saved and restored
     asm volatile(
@@ -92,7 +109,14 @@ __device__ __forceinline__ void dma16(const i32x4& rsrc, unsigned dst, int voff,
 // slot = 16 * group + kind; kinds: 0-5 phase 0 (issue, wait, barrier, mfma, barrier, -), 6-11 phase 1
 __device__ unsigned long long g_pp16_diag[2 * 512 * 32];   // [pooling variant][block][group][kind]
 __device__ unsigned long long g_pp16_clk[8];               // block 0: s_memtime / s_memrealtime at entry and exit, per variant
-#define PP_STAMP(k_)                                                                               \
+#if XVEC_DIAG == 2      // make DIAG=2: anatomy of the pooling epilogue only (kinds 0-5), K-loop stamps off
+#define PP_STAMP(k_)
+#define PP_ESTAMP(k_) PP_STAMP_DO(k_)
+#else
+#define PP_STAMP(k_) PP_STAMP_DO(k_)
+#define PP_ESTAMP(k_)
+#endif
+#define PP_STAMP_DO(k_)                                                                            \
     {                                                                                              \
         SB();                                                                                      \
         unsigned long long now_;                                                                   \
@@ -103,6 +127,7 @@ __device__ unsigned long long g_pp16_clk[8];               // block 0: s_memtime
     }
 #else
 #define PP_STAMP(k_)
+#define PP_ESTAMP(k_)
 #endif
 #ifdef XVEC_KNOCK
 // Timing-only knock-outs, compile time (-DXVEC_KNOCK=mask; results are garbage):
@@ -113,7 +138,13 @@ __device__ unsigned long long g_pp16_clk[8];               // block 0: s_memtime
 #define PP_KNOCK_EPI ((XVEC_KNOCK & 4) != 0)
 #define PP_KNOCK_RDW ((XVEC_KNOCK & 8) != 0)     // bit 3: no W fragment reads only
 #define PP_KNOCK_RDA ((XVEC_KNOCK & 16) != 0)    // bit 4: no A fragment reads only
+#define PP_KNOCK_MASKED ((XVEC_KNOCK & 32) != 0) // bit 5: pooling epilogue without its masked path (code-size experiment)
+#define PP_KNOCK_PARK ((XVEC_KNOCK & 64) != 0)   // bit 6: pooling epilogue without the LDS round trip of the running sums
+#define PP_KNOCK_ROWS ((XVEC_KNOCK & 128) != 0)  // bit 7: pooling epilogue on acc row 0 only
 #else
+#define PP_KNOCK_MASKED false
+#define PP_KNOCK_PARK false
+#define PP_KNOCK_ROWS false
 #define PP_KNOCK_RDW false
 #define PP_KNOCK_RDA false
 #define PP_KNOCK_DMA false
@@ -248,20 +279,20 @@ __device__ __forceinline__ void kstep(const TdnnArgs& a, KPos& k) {
 #define PP_ISSUE_W(b_, q_)                                                          \
     {                                                                               \
         const int so_ = (q_) * kWBytes;              /* K-tile major weights: 32 KiB per K-tile */ \
-        dma16(st.wrsrc, st.lds_w + (b_) * kBufBytes, st.wv0, so_);                  \
-        dma16(st.wrsrc, st.lds_w + (b_) * kBufBytes + 8 * 1024, st.wv0, so_ + st.w64);       \
-        dma16(st.wrsrc, st.lds_w + (b_) * kBufBytes + 16 * 1024, st.wv0, so_ + 2 * st.w64);  \
-        dma16(st.wrsrc, st.lds_w + (b_) * kBufBytes + 24 * 1024, st.wv0, so_ + 3 * st.w64);  \
+        dma16(st.wrsrc, st.lds_w + (b_) * kWBytes, st.wv0, so_);                  \
+        dma16(st.wrsrc, st.lds_w + (b_) * kWBytes + 8 * 1024, st.wv0, so_ + st.w64);       \
+        dma16(st.wrsrc, st.lds_w + (b_) * kWBytes + 16 * 1024, st.wv0, so_ + 2 * st.w64);  \
+        dma16(st.wrsrc, st.lds_w + (b_) * kWBytes + 24 * 1024, st.wv0, so_ + 3 * st.w64);  \
     }
 #define PP_ISSUE_A01(b_, so_)                                                       \
     {                                                                               \
-        dma16(st.cur.xrsrc, st.lds_a + (b_) * kBufBytes, st.cur.av0, so_);                  \
-        dma16(st.cur.xrsrc, st.lds_a + (b_) * kBufBytes + kAccRowB, st.cur.av1, so_);       \
+        dma16(st.cur.xrsrc, st.lds_a + (b_) * kABytes, st.cur.av0, so_);                  \
+        dma16(st.cur.xrsrc, st.lds_a + (b_) * kABytes + kAccRowB, st.cur.av1, so_);       \
     }
 #define PP_ISSUE_A23(MR_, b_, so_)                                                  \
     {                                                                               \
-        if ((MR_) > 2) dma16(st.cur.xrsrc, st.lds_a + (b_) * kBufBytes + 2 * kAccRowB, st.cur.av2, so_);   \
-        if ((MR_) > 3) dma16(st.cur.xrsrc, st.lds_a + (b_) * kBufBytes + 3 * kAccRowB, st.cur.av3, so_); \
+        if ((MR_) > 2) dma16(st.cur.xrsrc, st.lds_a + (b_) * kABytes + 2 * kAccRowB, st.cur.av2, so_);   \
+        if ((MR_) > 3) dma16(st.cur.xrsrc, st.lds_a + (b_) * kABytes + 3 * kAccRowB, st.cur.av3, so_); \
     }
 
 // first K-tiles of a tile: part 1 = all of K-tile 0; part 2 = all of K-tile 1, in the K loop's request order
@@ -287,6 +318,10 @@ struct Lane {
     int k0, k1;      // swizzled byte offset of this lane's 16-byte chunk for k-steps 0, 1
     unsigned a_rd;   // LDS byte offset (buffer 0) of this wave's group's acc row 0, + rd
     unsigned w_rd;   // LDS byte offset (buffer 0) of this wave's channel column 0, + rd
+    // the four base registers of every fragment read (operand x k-step), made opaque to the compiler: left to itself it
+    // re-associates the address sums around ONE base and then materialises a dozen "base + constant" registers for the
+    // constants that do not fit a ds_read's 16-bit offset field
+    unsigned a_k0, a_k1, w_k0, w_k1;
     int wave, grp, wc;
 };
 
@@ -296,11 +331,11 @@ constexpr int kBlk16 = 16 * kRowB;                // 16 rows of a 32-row block: 
 // W fragments of K-tile in buffer b_: 4 channel blocks x 2 k-steps
 #define PP_READ_W(b_)                                                     \
     {                                                                     \
-        const unsigned o_ = ln.w_rd + (b_) * kBufBytes;                   \
-        PP_RDW(wf0_0, o_ + ln.k0) PP_RDW(wf0_1, o_ + ln.k1)               \
-        PP_RDW(wf1_0, o_ + kBlk16 + ln.k0) PP_RDW(wf1_1, o_ + kBlk16 + ln.k1)          \
-        PP_RDW(wf2_0, o_ + 2 * kBlk16 + ln.k0) PP_RDW(wf2_1, o_ + 2 * kBlk16 + ln.k1)  \
-        PP_RDW(wf3_0, o_ + 3 * kBlk16 + ln.k0) PP_RDW(wf3_1, o_ + 3 * kBlk16 + ln.k1)  \
+        constexpr unsigned o_ = (b_) * kWBytes;                           \
+        PP_RDW(wf0_0, ln.w_k0 + o_) PP_RDW(wf0_1, ln.w_k1 + o_)               \
+        PP_RDW(wf1_0, ln.w_k0 + o_ + kBlk16) PP_RDW(wf1_1, ln.w_k1 + o_ + kBlk16)          \
+        PP_RDW(wf2_0, ln.w_k0 + o_ + 2 * kBlk16) PP_RDW(wf2_1, ln.w_k1 + o_ + 2 * kBlk16)  \
+        PP_RDW(wf3_0, ln.w_k0 + o_ + 3 * kBlk16) PP_RDW(wf3_1, ln.w_k1 + o_ + 3 * kBlk16)  \
     }
 // one MFMA: accumulator (acc row i_, frame block f_, channel block c_), k-step s_.  The activations are the MFMA A
 // operand: frames in the accumulator's registers (frame 4q + e), the channel on the lane.
@@ -320,7 +355,7 @@ constexpr int kBlk16 = 16 * kRowB;                // 16 rows of a 32-row block: 
 // one activation fragment read: acc row i_, frame block f_, k-step s_, from buffer b_.  A ds_read_b128 holds the
 // wave's issue for ~30 cycles (stamps, profiles/diag/pp_stamps.py), which is free exactly while MFMAs of this wave
 // are executing: ONE read behind every two MFMAs (32 cycles), never two in a row
-#define PP_RA(i_, f_, s_, b_) if constexpr (!PP_KNOCK_RDA) PP_RD(af##i_##_##f_##s_, ln.a_rd + (b_) * kBufBytes + (i_) * kAccRowB + (f_) * kBlk16 + ln.k##s_) SB();
+#define PP_RA(i_, f_, s_, b_) if constexpr (!PP_KNOCK_RDA) PP_RD(af##i_##_##f_##s_, ln.a_k##s_ + ((b_) * kABytes + (i_) * kAccRowB + (f_) * kBlk16)) SB();
 // half a quad followed by one read
 #define PP_H0R(i_, f_, s_, ri_, rf_, rs_, b_) PP_H0(i_, f_, s_) PP_RA(ri_, rf_, rs_, b_)
 #define PP_H1R(i_, f_, s_, ri_, rf_, rs_, b_) PP_H1(i_, f_, s_) PP_RA(ri_, rf_, rs_, b_)
@@ -440,6 +475,15 @@ __device__ __forceinline__ int64_t first_row(const RowMap& m, int u) {
     if (RAGGED) return sload_i64(m.offsets + u) - (int64_t)u * m.cum;
     return (int64_t)u * (m.fixed_T - m.cum);
 }
+// max(x, 0) as ONE instruction.  fmaxf() on a value hipcc cannot prove canonical (the accumulators come out of inline asm)
+// becomes v_max_f32 t, x, x; v_max_f32 r, 0, t -- a quieting pass plus the max, the second waiting for the first: twice
+// the instructions of the epilogues' ReLU, in dependent pairs.  (A NaN gives 0 here, as fmaxf does.)
+__device__ __forceinline__ float relu1(float x) {
+    float r;
+    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+
 // --- cross-lane helpers for the 16x16 accumulator layout (frames on the four lane quads q = l >> 4) --------------
 // {a summed over the two lane halves | b summed over the two lane halves}: v_permlane32_swap(a, b) returns
 // {a.lo | b.lo, a.hi | b.hi}; their sum holds a's total in the lower half and b's in the upper half
@@ -460,89 +504,143 @@ __device__ __forceinline__ float quad0(float x) {
     return lower_half(__uint_as_float(r[0]));
 }
 
-// One partial (tdnn_common.h: planes K | S1 | S2) of the lane's four adjacent columns col0..col0+3.  Every lane
-// quad holds the sums of ITS eight frames; the eight numbers (S1, S2 x 4 columns) are reduced over the quads as a
-// reduce-scatter -- four v_permlane32_swap + two v_permlane16_swap and six adds, after which quad 0 holds S1 of
-// columns 0,1, quad 2 S1 of columns 2,3, quad 1 S2 of columns 0,1 and quad 3 S2 of columns 2,3 -- and ONE 8-byte
-// store writes 256 contiguous bytes of the S1 plane and 256 of the S2 plane; quad 0 writes the pivots (16 bytes
-// per lane, 256 contiguous bytes of the K plane).
-__device__ __forceinline__ void store_quads(__amdgpu_buffer_rsrc_t prs, int ld, int64_t slot, int q, int col0, const f32x4& k,
-                                            const f32x4& s1, const f32x4& s2) {
+// ---- fused statistics pooling, accumulated per UTTERANCE SEGMENT ------------------------------------------------
+// A block owns a contiguous row range of its column (~27 units of 64 frames at the bench batch: six utterances), and a
+// wave sees the rows of its group (frames half) of every tile in increasing order.  So a wave keeps the running sums
+// of its CURRENT utterance -- pivot K, S1 = sum (r - K), S2 = sum (r - K)^2 per lane and channel, r = relu(z + bias) --
+// across tiles (parked in LDS during the K loops: the loop has no register to spare) and writes ONE partial per
+// (block, group, utterance): 2 x (blocks per column + utterances) slots instead of one per 32-frame group (47 MB ->
+// 11 MB at the bench batch), no cross-lane traffic and no store in the common case: per value one v_max and half a
+// v_pk_add (pivot), v_pk_add, v_pk_fma.  Layout of a slot: tdnn_common.h's three planes K | S1 | S2 of n_pad floats;
+// slot of (block b of the column, utterance u, group g) = 2 (b + u) + g -- b and u both grow along the rows, so
+// consecutive segments get distinct slots -- and the number of frames behind a partial goes to pool_cnt[slot]
+// (pool_finalize_seg needs it to re-base the pivots).  Every wave writes a partial, possibly of zero frames, for EVERY
+// utterance that overlaps its block's row range: pool_finalize_seg reads exactly those.
+// The pivot of a segment is frame 0 of the 32-frame group in which the segment's first rows fall (a computed row
+// of the same channel, this utterance's or its neighbour's: tdnn_common.h, pool_group_impl on why that is enough).
+struct Seg {
+    f32x4 k, s1, s2;            // per lane: its four channels
+};
+
+// flush: reduce S1, S2 over the four lane quads (reduce-scatter: four v_permlane32_swap + two v_permlane16_swap, six
+// adds; afterwards quad 0 holds S1 of columns 0,1, quad 2 S1 of columns 2,3, quad 1 S2 of columns 0,1, quad 3 S2 of
+// columns 2,3) and write the slot: ONE 8-byte store = 256 contiguous bytes of the S1 plane and 256 of the S2 plane;
+// quad 0 writes the pivots (16 bytes per lane); one lane of the block's first column writes the frame count.
+__device__ __forceinline__ void flush_seg(const TdnnArgs& a, Seg& sg, int slot, int n_rows, int q, int col0, bool cnt_writer) {
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-    const float y0 = swap32_add(s1[0], s1[2]), y1 = swap32_add(s2[0], s2[2]);
-    const float y2 = swap32_add(s1[1], s1[3]), y3 = swap32_add(s2[1], s2[3]);
+    const __amdgpu_buffer_rsrc_t prs = make_rsrc(a.pool_part);
+    const int ld = a.ldy;
+    const float y0 = swap32_add(sg.s1[0], sg.s1[2]), y1 = swap32_add(sg.s2[0], sg.s2[2]);
+    const float y2 = swap32_add(sg.s1[1], sg.s1[3]), y3 = swap32_add(sg.s2[1], sg.s2[3]);
     const float z0 = swap16_add(y0, y1), z1 = swap16_add(y2, y3);
-    const int soff = (int)(slot * kPoolPlanes * ld) * 4;
+    const int soff = slot * kPoolPlanes * ld * 4;
     const u32x2 v = {__float_as_uint(z0), __float_as_uint(z1)};
     __builtin_amdgcn_raw_buffer_store_b64(v, prs, (col0 + (q >> 1) * 2 + (1 + (q & 1)) * ld) * 4, soff, 0);
     if (q == 0) {
-        const u32x4 kv = {__float_as_uint(k[0]), __float_as_uint(k[1]), __float_as_uint(k[2]), __float_as_uint(k[3])};
+        const u32x4 kv = {__float_as_uint(sg.k[0]), __float_as_uint(sg.k[1]), __float_as_uint(sg.k[2]), __float_as_uint(sg.k[3])};
         __builtin_amdgcn_raw_buffer_store_b128(kv, prs, col0 * 4, soff, 0);
         asm volatile("s_nop 1" ::"v"(kv));       // the 128-bit-store data hazard (tdnn_common.h, store_acc)
     }
+    if (cnt_writer) a.pool_cnt[slot] = n_rows;
+    sg.k = f32x4{0.f, 0.f, 0.f, 0.f};
+    sg.s1 = sg.k;
+    sg.s2 = sg.k;
 }
 
-// v{f}{c}: the accumulator of frame block f (frames 16 f + 4 q + e) and channel col0 + c, bias inside.
+// cursor of a wave: utterance being accumulated, its end row, frames of it accumulated so far (all wave-uniform)
+struct SegCur {
+    int u;
+    int n;
+    int64_t end;
+};
+
+// One 32-frame group of this wave (acc row): v{f}{c} = accumulator of frame block f (frames 16 f + 4 q + e) and channel
+// col0 + c, bias inside.  limit = first row that does not belong to this block (its range end, or the end of the batch).
 template <bool RAGGED>
-__device__ __forceinline__ void pool_quads(const TdnnArgs& a, const f32x4& v00, const f32x4& v01, const f32x4& v02,
-                                           const f32x4& v03, const f32x4& v10, const f32x4& v11, const f32x4& v12,
-                                           const f32x4& v13, int64_t row_g, int q, int col0, PoolCur& pc) {
+__device__ __forceinline__ void pool_rows(const TdnnArgs& a, f32x4& v00, f32x4& v01, f32x4& v02, f32x4& v03, f32x4& v10,
+                                          f32x4& v11, f32x4& v12, f32x4& v13, int64_t row_g, int64_t limit, int q, int col0,
+                                          int blk, int grp, bool cnt_writer, SegCur& sc, Seg& sg) {
     const RowMap& m = a.out_map;
-    while (pc.end <= row_g && pc.u < m.n_utts - 1) {
-        pc.u = __builtin_amdgcn_readfirstlane(pc.u + 1);
-        pc.end = first_row<RAGGED>(m, pc.u + 1);
+    if (row_g >= limit) return;
+    // r = relu(z + bias), IN PLACE: as an expression in both paths below hipcc computes the 32 values up front into
+    // 32 more registers, next to 128 live accumulators
+#define PQ_RELU(v_) _Pragma("unroll") for (int e = 0; e < 4; ++e) v_[e] = relu1(v_[e]);
+    PQ_RELU(v00) PQ_RELU(v01) PQ_RELU(v02) PQ_RELU(v03) PQ_RELU(v10) PQ_RELU(v11) PQ_RELU(v12) PQ_RELU(v13)
+#undef PQ_RELU
+    const int64_t g_end = row_g + 32 < limit ? row_g + 32 : limit;
+    // utterances that ended before this group (the current one, and any that lay wholly in the other group's rows)
+    while (sc.end <= row_g && sc.u < m.n_utts - 1) {
+        flush_seg(a, sg, 2 * (blk + sc.u) + grp, sc.n, q, col0, cnt_writer);
+        sc.u = __builtin_amdgcn_readfirstlane(sc.u + 1);
+        sc.n = 0;
+        sc.end = first_row<RAGGED>(m, sc.u + 1);
     }
-    const int64_t grp = row_g >> 5;
-    const int ld = a.ldy;
-    const __amdgpu_buffer_rsrc_t prs = make_rsrc(a.pool_part);
-    // pivots: the group's frame 0 (quad 0, frame block 0, register 0) of the lane's four channels (tdnn_common.h,
-    // pool_group_impl: why a pivot)
-    const f32x4 k = {quad0(fmaxf(v00[0], 0.f)), quad0(fmaxf(v01[0], 0.f)), quad0(fmaxf(v02[0], 0.f)), quad0(fmaxf(v03[0], 0.f))};
-    if (pc.end >= row_g + 32) {               // the whole group belongs to utterance pc.u
-        f32x4 s1, s2;
-        // two values per instruction where the ISA has one (v_pk_add_f32 / v_pk_fma_f32; the max has none)
-#define PQ_SUM(c_)                                                                                            \
-        {                                                                                                     \
-            const f32x2 kk = {k[c_], k[c_]};                                                                  \
-            const f32x2 d0 = f32x2{fmaxf(v0##c_[0], 0.f), fmaxf(v0##c_[1], 0.f)} - kk;                         \
-            const f32x2 d1 = f32x2{fmaxf(v0##c_[2], 0.f), fmaxf(v0##c_[3], 0.f)} - kk;                         \
-            const f32x2 d2 = f32x2{fmaxf(v1##c_[0], 0.f), fmaxf(v1##c_[1], 0.f)} - kk;                         \
-            const f32x2 d3 = f32x2{fmaxf(v1##c_[2], 0.f), fmaxf(v1##c_[3], 0.f)} - kk;                         \
-            const f32x2 p1 = (d0 + d1) + (d2 + d3);                                                           \
-            f32x2 p2 = d0 * d0;                                                                               \
-            p2 = __builtin_elementwise_fma(d1, d1, p2);                                                       \
-            p2 = __builtin_elementwise_fma(d2, d2, p2);                                                       \
-            p2 = __builtin_elementwise_fma(d3, d3, p2);                                                       \
-            s1[c_] = p1.x + p1.y;                                                                             \
-            s2[c_] = p2.x + p2.y;                                                                             \
-        }
-        PQ_SUM(0) PQ_SUM(1) PQ_SUM(2) PQ_SUM(3)
-#undef PQ_SUM
-        store_quads(prs, ld, grp + pc.u, q, col0, k, s1, s2);
-        return;
-    }
-    for (int u = pc.u; u < m.n_utts; u = __builtin_amdgcn_readfirstlane(u + 1)) {   // the group straddles utterances
-        const int64_t off = first_row<RAGGED>(m, u);
-        if (off >= row_g + 32) break;
-        const int64_t end = first_row<RAGGED>(m, u + 1);
-        const int64_t lo_r = off > row_g ? off : row_g;
-        const int64_t hi_r = end < row_g + 32 ? end : row_g + 32;
-        if (hi_r <= lo_r) continue;
-        const int lo_l = (int)(lo_r - row_g), hi_l = (int)(hi_r - row_g);
-        const unsigned below_hi = hi_l >= 32 ? 0xffffffffu : ((1u << hi_l) - 1u);
-        const unsigned lm = (below_hi & ~((1u << lo_l) - 1u)) >> (4 * q);   // this lane's frames: bits 16 f + e
-        f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+    int64_t lo = row_g;
+    for (;;) {
+        const int64_t hi = sc.end < g_end ? sc.end : g_end;           // rows [lo, hi) of the group belong to sc.u
+        if (hi > lo) {
+            if (sc.n == 0) {                                          // the segment's first rows: take the pivots
+                sg.k = f32x4{quad0(v00[0]), quad0(v01[0]), quad0(v02[0]), quad0(v03[0])};
+            }
+            if (hi - lo == 32 || PP_KNOCK_MASKED) {                   // the whole group: no masks
+                // plain v_sub / v_add / v_fma (v_pk_*_f32 issue at ~17 cycles each: MI355X_MICROARCH.md, price of fillers;
+                // -fno-slp-vectorize keeps hipcc from re-packing them), the four channels' chains interleaved so that no
+                // instruction waits for the one before it
+                f32x4 t1 = {0.f, 0.f, 0.f, 0.f}, t2 = {0.f, 0.f, 0.f, 0.f};
+#define PQ_STEP(f_, e_)                                                                                       \
+                {                                                                                             \
+                    const float d0 = v##f_##0[e_] - sg.k[0], d1 = v##f_##1[e_] - sg.k[1];                      \
+                    const float d2 = v##f_##2[e_] - sg.k[2], d3 = v##f_##3[e_] - sg.k[3];                      \
+                    t1[0] += d0; t1[1] += d1; t1[2] += d2; t1[3] += d3;                                       \
+                    t2[0] = fmaf(d0, d0, t2[0]); t2[1] = fmaf(d1, d1, t2[1]);                                 \
+                    t2[2] = fmaf(d2, d2, t2[2]); t2[3] = fmaf(d3, d3, t2[3]);                                 \
+                }
+                PQ_STEP(0, 0) PQ_STEP(0, 1) PQ_STEP(0, 2) PQ_STEP(0, 3) PQ_STEP(1, 0) PQ_STEP(1, 1) PQ_STEP(1, 2) PQ_STEP(1, 3)
+#undef PQ_STEP
+                sg.s1 += t1;
+                sg.s2 += t2;
+            } else {
+                const int lo_l = (int)(lo - row_g), hi_l = (int)(hi - row_g);       // local rows [lo_l, hi_l), hi_l - lo_l < 32
+                const unsigned below_hi = hi_l >= 32 ? 0xffffffffu : ((1u << hi_l) - 1u);
+                const unsigned lm = (below_hi & ~((1u << lo_l) - 1u)) >> (4 * q);   // this lane's frames: bits 16 f + e
+                // (the pivots go through an opaque copy here: with the same SSA value in both paths hipcc computes all 32
+                //  differences v - k up front, shared by the two paths, into 32 more registers next to 128 live accumulators)
+                f32x4 km = sg.k;
+                asm volatile("" : "+v"(km));
 #define PQ_MASKED(f_, c_)                                                                                     \
-        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                       \
-            const bool in = (lm >> (16 * f_ + e)) & 1u;          /* a SELECT: rows outside may hold anything */ \
-            const float d = in ? fmaxf(v##f_##c_[e], 0.f) - k[c_] : 0.f;                                       \
-            s1[c_] += d;                                                                                      \
-            s2[c_] = fmaf(d, d, s2[c_]);                                                                      \
-        }
-        PQ_MASKED(0, 0) PQ_MASKED(1, 0) PQ_MASKED(0, 1) PQ_MASKED(1, 1)
-        PQ_MASKED(0, 2) PQ_MASKED(1, 2) PQ_MASKED(0, 3) PQ_MASKED(1, 3)
+                _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                               \
+                    const bool in = (lm >> (16 * f_ + e)) & 1u;      /* a SELECT: rows outside may hold anything */ \
+                    const float d = in ? v##f_##c_[e] - km[c_] : 0.f;                                          \
+                    sg.s1[c_] += d;                                                                           \
+                    sg.s2[c_] = fmaf(d, d, sg.s2[c_]);                                                        \
+                }
+                PQ_MASKED(0, 0) PQ_MASKED(1, 0) PQ_MASKED(0, 1) PQ_MASKED(1, 1)
+                PQ_MASKED(0, 2) PQ_MASKED(1, 2) PQ_MASKED(0, 3) PQ_MASKED(1, 3)
 #undef PQ_MASKED
-        store_quads(prs, ld, grp + u, q, col0, k, s1, s2);
+            }
+            sc.n += (int)(hi - lo);
+        }
+        if (sc.end >= g_end || sc.u >= m.n_utts - 1) break;          // the utterance goes on past this group
+        flush_seg(a, sg, 2 * (blk + sc.u) + grp, sc.n, q, col0, cnt_writer);   // it ended inside the group
+        sc.u = __builtin_amdgcn_readfirstlane(sc.u + 1);
+        sc.n = 0;
+        sc.end = first_row<RAGGED>(m, sc.u + 1);
+        lo = hi;
+    }
+}
+
+// end of the block: the current utterance, and every later one that still begins inside the block's rows (seen by the
+// other group only), get their partial
+template <bool RAGGED>
+__device__ __forceinline__ void pool_finish(const TdnnArgs& a, int64_t limit, int q, int col0, int blk, int grp,
+                                            bool cnt_writer, SegCur& sc, Seg& sg) {
+    const RowMap& m = a.out_map;
+    for (;;) {
+        flush_seg(a, sg, 2 * (blk + sc.u) + grp, sc.n, q, col0, cnt_writer);
+        sc.n = 0;
+        if (sc.u >= m.n_utts - 1 || sc.end >= limit) break;
+        sc.u = __builtin_amdgcn_readfirstlane(sc.u + 1);
+        sc.end = first_row<RAGGED>(m, sc.u + 1);
     }
 }
 
@@ -550,7 +648,7 @@ __device__ __forceinline__ void pool_quads(const TdnnArgs& a, const f32x4& v00, 
 template <int MR, bool POOL>
 __device__ __forceinline__ void process_tile(const TdnnArgs& a, char* smem, Stream& st, const Lane& ln,
                                              const Tile& t, const Tile& nxt, bool has_next, bool first, int n0, int nk,
-                                             PoolCur& pc) {
+                                             SegCur& sc, int64_t limit, int blk) {
     // source rows of the NEXT tile (its first K-tiles are requested during this tile's last two): worked out
     // here, before the accumulators exist, and parked in four registers
     Rows rows_next = st.cur;
@@ -632,6 +730,7 @@ __device__ __forceinline__ void process_tile(const TdnnArgs& a, char* smem, Stre
     if (ln.grp == 0) PP_BARRIER()
     PP_MFMA_SETTLE();
     PP_STAMP(13)                            // tail barrier
+    PP_ESTAMP(13)                           // (DIAG=2: everything up to here)
     PP_STAMP(5)
 
     const int64_t row0 = t.m0 + ln.grp * 32 * MR;
@@ -648,14 +747,17 @@ __device__ __forceinline__ void process_tile(const TdnnArgs& a, char* smem, Stre
         typedef float f32x2v __attribute__((ext_vector_type(2)));
         typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
         const __amdgpu_buffer_rsrc_t yrsrc = make_rsrc(static_cast<char*>(a.Y) + (t.m0 * (int64_t)a.ldy + n0) * 2);
-        const int y_voff = (4 * ln.q * a.ldy + ln.wc * 64 + 4 * ln.r) * 2;
-        const float4 sc = *reinterpret_cast<const float4*>(cst + 256), sh = *reinterpret_cast<const float4*>(cst + 512);
+        int lane_e;           // opaque lane id: see the pooling epilogue
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
+        const int y_voff = (4 * (lane_e >> 4) * a.ldy + ln.wc * 64 + 4 * (lane_e & 15)) * 2;
+        const float* cst_e = reinterpret_cast<const float*>(smem + kConstOff) + ln.wc * 64 + 4 * (lane_e & 15);
+        const float4 sc = *reinterpret_cast<const float4*>(cst_e + 256), sh = *reinterpret_cast<const float4*>(cst_e + 512);
 #define PP_STORE_F(i_, f_)                                                                             \
             _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                               \
-                const float v0 = fmaf(fmaxf(acc##i_##f_##0[e], 0.f), sc.x, sh.x);                         \
-                const float v1 = fmaf(fmaxf(acc##i_##f_##1[e], 0.f), sc.y, sh.y);                         \
-                const float v2 = fmaf(fmaxf(acc##i_##f_##2[e], 0.f), sc.z, sh.z);                         \
-                const float v3 = fmaf(fmaxf(acc##i_##f_##3[e], 0.f), sc.w, sh.w);                         \
+                const float v0 = fmaf(relu1(acc##i_##f_##0[e]), sc.x, sh.x);                         \
+                const float v1 = fmaf(relu1(acc##i_##f_##1[e]), sc.y, sh.y);                         \
+                const float v2 = fmaf(relu1(acc##i_##f_##2[e]), sc.z, sh.z);                         \
+                const float v3 = fmaf(relu1(acc##i_##f_##3[e]), sc.w, sh.w);                         \
                 const u32x2 pk = {__builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{v0, v1}, bf16x2)), \
                                   __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{v2, v3}, bf16x2))}; \
                 __builtin_amdgcn_raw_buffer_store_b64(pk, yrsrc, y_voff,                                  \
@@ -667,18 +769,46 @@ __device__ __forceinline__ void process_tile(const TdnnArgs& a, char* smem, Stre
 #undef PP_STORE
 #undef PP_STORE_F
     } else {
-        const int col0 = n0 + ln.wc * 64 + 4 * ln.r;
-#define PP_POOL(RG_, i_)                                                                               \
-        if (MR > i_ && row0 + 32 * i_ < t.valid_end) {                                                    \
-            pool_quads<RG_>(a, acc##i_##00, acc##i_##01, acc##i_##02, acc##i_##03, acc##i_##10, acc##i_##11, acc##i_##12, \
-                            acc##i_##13, row0 + 32 * i_, ln.q, col0, pc);                                 \
+        // (lane-derived values of this epilogue come from an opaque lane id: computed from ln.* the compiler hoists them
+        //  out of the tile loop and carries them through the K loop, which has no register to spare)
+        int lane_e;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
+        const int q_e = lane_e >> 4, r_e = lane_e & 15;
+        const int col0 = n0 + ln.wc * 64 + 4 * r_e;
+        const bool cnt_writer = n0 == 0 && ln.wc == 0 && lane_e == 0;
+        // the running sums of the wave's current utterance come back from their LDS slots
+        char* park = smem + kParkOff + (ln.wave * 64 + lane_e) * 48;
+        Seg sg;
+        if constexpr (PP_KNOCK_PARK) {
+            sg.k = f32x4{0.f, 0.f, 0.f, 0.f};
+            sg.s1 = sg.k;
+            sg.s2 = sg.k;
+        } else {
+            sg.k = *reinterpret_cast<const f32x4*>(park);
+            sg.s1 = *reinterpret_cast<const f32x4*>(park + 16);
+            sg.s2 = *reinterpret_cast<const f32x4*>(park + 32);
         }
+        PP_ESTAMP(0)
+#define PP_POOL(RG_, i_)                                                                               \
+        if (MR > i_ && !(PP_KNOCK_ROWS && i_ > 0))                                                        \
+            pool_rows<RG_>(a, acc##i_##00, acc##i_##01, acc##i_##02, acc##i_##03, acc##i_##10, acc##i_##11, acc##i_##12, \
+                           acc##i_##13, row0 + 32 * i_, limit, q_e, col0, blk, ln.grp, cnt_writer, sc, sg);
         if (a.out_map.offsets == nullptr) {
-            PP_POOL(false, 0) PP_POOL(false, 1) PP_POOL(false, 2) PP_POOL(false, 3)
+            PP_POOL(false, 0) PP_ESTAMP(1) PP_POOL(false, 1) PP_ESTAMP(2) PP_POOL(false, 2) PP_ESTAMP(3) PP_POOL(false, 3) PP_ESTAMP(4)
+            if (!has_next) pool_finish<false>(a, limit, q_e, col0, blk, ln.grp, cnt_writer, sc, sg);
         } else {
             PP_POOL(true, 0) PP_POOL(true, 1) PP_POOL(true, 2) PP_POOL(true, 3)
+            if (!has_next) pool_finish<true>(a, limit, q_e, col0, blk, ln.grp, cnt_writer, sc, sg);
         }
 #undef PP_POOL
+        if constexpr (!PP_KNOCK_PARK) {
+            *reinterpret_cast<f32x4*>(park) = sg.k;
+            *reinterpret_cast<f32x4*>(park + 16) = sg.s1;
+            *reinterpret_cast<f32x4*>(park + 32) = sg.s2;
+        } else {
+            asm volatile("" ::"v"(sg.k), "v"(sg.s1), "v"(sg.s2));
+        }
+        PP_ESTAMP(5)
     }
 #undef PP_ACCV
 #undef PP_ACCS
@@ -730,7 +860,12 @@ __global__ __launch_bounds__(kThreads, 2) void tdnn_pp_kernel(const TdnnArgs a) 
         ln.k1 = ((4 + ln.q) ^ sw) << 4;
     }
     ln.a_rd = ln.grp * 4 * kAccRowB + ln.rd;
-    ln.w_rd = kABytes + ln.wc * 2 * kAccRowB + ln.rd;
+    ln.w_rd = kWOff + ln.wc * 2 * kAccRowB + ln.rd;
+    ln.a_k0 = ln.a_rd + ln.k0;
+    ln.a_k1 = ln.a_rd + ln.k1;
+    ln.w_k0 = ln.w_rd + ln.k0;
+    ln.w_k1 = ln.w_rd + ln.k1;
+    asm volatile("" : "+v"(ln.a_k0), "+v"(ln.a_k1), "+v"(ln.w_k0), "+v"(ln.w_k1));
 
     // per-channel constants of the block's column -> LDS
     if (tid < 192) {
@@ -748,7 +883,7 @@ __global__ __launch_bounds__(kThreads, 2) void tdnn_pp_kernel(const TdnnArgs a) 
         st.lds_a = (unsigned)(unsigned long long)(lds_ptr)(smem) + ln.grp * 4 * kAccRowB + ln.wc * 1024;
         const int wr = ln.wave * 8 + prow;                                // W: channel row of piece t = wr + 64*t
         const int w_chunk = (ppos ^ ((wr >> 1) & 7)) * 16;                // ((wr + 64t) >> 1) & 7 is the same for every t
-        st.lds_w = (unsigned)(unsigned long long)(lds_ptr)(smem) + kABytes + ln.wave * 1024;
+        st.lds_w = (unsigned)(unsigned long long)(lds_ptr)(smem) + kWOff + ln.wave * 1024;
         st.wv0 = wr * kRowB + w_chunk;                                    // K-tile major: rows 128 B apart
         st.w64 = 64 * kRowB;
         st.wrsrc = make_srd(static_cast<const char*>(a.W) + (int64_t)jcol * nk * kWBytes);
@@ -756,9 +891,10 @@ __global__ __launch_bounds__(kThreads, 2) void tdnn_pp_kernel(const TdnnArgs a) 
         st.u_tile = __builtin_amdgcn_readfirstlane(utt_of_row(a.out_map, u_begin * 64));
         st.off_next = row_off(a.out_map, st.u_tile + 1);
         st.cur.xrsrc = st.wrsrc;
-        PoolCur pc;
-        pc.u = 0;
-        pc.end = 0;
+        SegCur sc;
+        sc.u = 0;
+        sc.n = 0;
+        sc.end = 0;
 
         // tiles of this block: n units cut into ceil(n/4) tiles of 4, 3 or 2 units, as equal as possible (5 = 3 + 2:
         // without the 2-unit tile a batch of 128 utterances ran slower than one of 96); n = 1: one 2-unit tile whose
@@ -779,7 +915,20 @@ __global__ __launch_bounds__(kThreads, 2) void tdnn_pp_kernel(const TdnnArgs a) 
             return t;
         };
         Tile cur = tile_at(0, u_begin * 64);
-        if (POOL) pc = pool_cursor(a, cur.m0 + ln.grp * 32 * cur.mr);
+        int64_t limit = range_end;                       // first row that is not this block's: its range end or the batch end
+        if (POOL) {
+            // both groups start at the utterance of the block's FIRST row (a wave flushes an empty partial for every
+            // utterance its own rows skip)
+            const PoolCur pc0 = pool_cursor(a, u_begin * 64);
+            sc.u = pc0.u;
+            sc.end = pc0.end;
+            const int64_t total_rows = row_off(a.out_map, a.out_map.n_utts);
+            limit = range_end < total_rows ? range_end : total_rows;
+            f32x4* park = reinterpret_cast<f32x4*>(smem + kParkOff + tid * 48);
+            park[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+            park[1] = park[0];
+            park[2] = park[0];
+        }
         set_rows(a, cur, ln.grp, ln.wc, st, st.cur);
         __syncthreads();                                   // constants visible; nobody reads LDS buffers yet
         issue_head1<POOL>(a, st, cur.mr);
@@ -789,11 +938,11 @@ __global__ __launch_bounds__(kThreads, 2) void tdnn_pp_kernel(const TdnnArgs a) 
             Tile nxt = cur;
             if (has_next) nxt = tile_at(idx + 1, cur.m0 + 64 * cur.mr);
             if (cur.mr == 4)
-                process_tile<4, POOL>(a, smem, st, ln, cur, nxt, has_next, idx == 0, n0, nk, pc);
+                process_tile<4, POOL>(a, smem, st, ln, cur, nxt, has_next, idx == 0, n0, nk, sc, limit, prange);
             else if (cur.mr == 3)
-                process_tile<3, POOL>(a, smem, st, ln, cur, nxt, has_next, idx == 0, n0, nk, pc);
+                process_tile<3, POOL>(a, smem, st, ln, cur, nxt, has_next, idx == 0, n0, nk, sc, limit, prange);
             else
-                process_tile<2, POOL>(a, smem, st, ln, cur, nxt, has_next, idx == 0, n0, nk, pc);
+                process_tile<2, POOL>(a, smem, st, ln, cur, nxt, has_next, idx == 0, n0, nk, sc, limit, prange);
             cur = nxt;
         }
 #ifdef XVEC_DIAG

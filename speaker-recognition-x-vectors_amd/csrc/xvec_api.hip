@@ -2,6 +2,7 @@
 // workspace planning and the launch sequence of the extraction path.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -86,6 +87,8 @@ struct xvec_handle {
     int offs_next;
     int num_cu;
     int blocks_per_cu;                 // persistent TDNN blocks per CU (LDS allows 2)
+    int64_t pool_units;                // geometry of the last tdnn_pp launch (pool_finalize's segment form needs it)
+    int pool_bpc;
     int last_kernel[XVEC_NUM_TDNN];    // XVEC_KERNEL_* the last launch of each frame-level layer went to (xvec_get_dispatch)
     // profiling
     bool profiling;
@@ -97,7 +100,7 @@ namespace {
 
 struct Plan {
     int64_t total, m_pad, rows_alloc;
-    size_t xpad, x16, actA, actB, act5, part, pooled, seg6, seg7, offs, bytes;
+    size_t xpad, x16, actA, actB, act5, part, part_cnt, pooled, seg6, seg7, offs, bytes;
     int64_t part_slots;
 };
 
@@ -115,8 +118,10 @@ Plan make_plan(const xvec_handle* h, int64_t total, int B) {
     p.actA = o;   o += align_up((size_t)p.rows_alloc * nh * 4);
     p.actB = o;   o += align_up((size_t)p.rows_alloc * nh * 4);
     p.act5 = o;   o += align_up((size_t)p.rows_alloc * (n5 > nh ? n5 : nh) * 4);   // also the fp32 output of xvec_tdnn_layer
-    p.part_slots = p.m_pad / 32 + B + 1;
+    // pooling partials: one per (32-row group, utterance) -- or, tdnn_pp16.hip, two per (block of a column, utterance)
+    p.part_slots = std::max<int64_t>(p.m_pad / 32 + B + 1, 2 * ((int64_t)h->num_cu + B) + 2);
     p.part = o;   o += align_up((size_t)p.part_slots * 3 * n5 * 4);   // (addressed with 32-bit offsets: forward_rows checks < 2 GiB)
+    p.part_cnt = o; o += align_up((size_t)2 * (h->num_cu + B + 2) * 4);     // tdnn_pp16.hip: frames behind each segment partial
     p.pooled = o; o += align_up((size_t)B * 2 * XVEC_POOL_CHANNELS * 4);
     p.seg6 = o;   o += align_up((size_t)B * h->cfg.x_vector_size * 4);
     p.seg7 = o;   o += align_up((size_t)B * h->cfg.x_vector_size * 4);
@@ -179,7 +184,7 @@ struct StageTimer {
 // x3: bf16x3 arithmetic -- X (and Y, when it is bf16) are two bf16 planes `x_plane` / `y_plane` bytes apart
 int run_tdnn(xvec_handle* h, int layer, TdnnVariant v, const void* X, int ldx, int64_t x_rows, void* Y,
              int64_t rows_out, const RowMap& out_map, float* part, hipStream_t s, bool x3 = false,
-             int64_t x_plane = 0, int64_t y_plane = 0) {
+             int64_t x_plane = 0, int64_t y_plane = 0, int* part_cnt = nullptr) {
     const bool in16 = v == TdnnVariant::kBf16 || v == TdnnVariant::kBf16Pool || v == TdnnVariant::kBf16ToF32 ||
                       v == TdnnVariant::kBf16First || v == TdnnVariant::kBf16FirstToF32 || v == TdnnVariant::kBf16FirstSrc32;
     const TdnnGeom& g = in16 ? h->geo16[layer] : h->geo[layer];
@@ -214,6 +219,7 @@ int run_tdnn(xvec_handle* h, int layer, TdnnVariant v, const void* X, int ldx, i
         a.pair_period = ok ? (nwg / 8) / a.n_tiles : 0;
     }
     a.pool_part = part;
+    a.pool_cnt = part_cnt;
     a.out_map = out_map;
     a.span = h->geo[layer].ctx_span;
     a.terms = 1;
@@ -250,6 +256,8 @@ int run_tdnn(xvec_handle* h, int layer, TdnnVariant v, const void* X, int ldx, i
             a.blocks_per_col = bpc;
             a.groups_total = units;
             a.pair_period = 0;
+            h->pool_units = units;
+            h->pool_bpc = bpc;
             if (h->pp_shape == 16) HIP_TRY(launch_tdnn_pp16(a, v == TdnnVariant::kBf16Pool, s));
             else HIP_TRY(launch_tdnn_pp(a, v == TdnnVariant::kBf16Pool, s));
             h->last_kernel[layer] = XVEC_KERNEL_PP;
@@ -277,12 +285,34 @@ int check_loaded(const xvec_handle* h, int mode) {
     return XVEC_OK;
 }
 
+// merge the pooling partials layer 5 left (in the form of the kernel that ran: xvec_get_dispatch) into pooled[B, 3000]
+int finalize_pool(xvec_handle* h, const float* part, const int* part_cnt, const RowMap& map, float* pooled, hipStream_t s) {
+    PoolFinalizeArgs f;
+    memset(&f, 0, sizeof(f));
+    f.part = part;
+    f.out = pooled;
+    f.map = map;
+    f.C = XVEC_POOL_CHANNELS;
+    f.n_pad = h->geo[4].n_pad;
+    f.sub_rows = 32;
+    f.scale = h->vec[4] + f.n_pad;              // the pooling epilogues leave sums of r = relu(z + bias)
+    f.shift = h->vec[4] + 2 * f.n_pad;
+    if (h->last_kernel[4] == XVEC_KERNEL_PP && h->pp_shape == 16) {     // tdnn_pp16.hip: one partial per (block, utterance, half)
+        f.cnt = part_cnt;
+        f.units_total = h->pool_units;
+        f.blocks_per_col = h->pool_bpc;
+    }
+    HIP_TRY(launch_pool_finalize(f, s));
+    return XVEC_OK;
+}
+
 // x_rows: [total, ldx] packed rows (offs_host == nullptr: B utterances of fixed_T rows each)
 int forward_rows(xvec_handle* h, const float* x_rows, int ldx, const int64_t* offs_dev, int B, int fixed_T,
                  const Plan& p, int mode, int dtype, float* out, char* ws, hipStream_t s) {
     float* actA = reinterpret_cast<float*>(ws + p.actA);
     float* actB = reinterpret_cast<float*>(ws + p.actB);
     float* part = reinterpret_cast<float*>(ws + p.part);
+    int* part_cnt = reinterpret_cast<int*>(ws + p.part_cnt);
     float* pooled = mode == XVEC_MODE_POOLED ? out : reinterpret_cast<float*>(ws + p.pooled);
     float* s6 = reinterpret_cast<float*>(ws + p.seg6);
     float* s7 = reinterpret_cast<float*>(ws + p.seg7);
@@ -327,7 +357,7 @@ int forward_rows(xvec_handle* h, const float* x_rows, int ldx, const int64_t* of
         const TdnnVariant v = l == 0 ? v1 : l == 4 ? v5 : vm;
         void* out_buf = l == 4 ? nullptr : bufs[l & 1];
         if ((rc = run_tdnn(h, l, v, in, ld_in, l == 0 ? p.total : 0, out_buf, rows_out, map, l == 4 ? part : nullptr, s,
-                           x3, in_plane, l == 4 ? 0 : act_plane)))
+                           x3, in_plane, l == 4 ? 0 : act_plane, l == 4 ? part_cnt : nullptr)))
             return rc;
         in = out_buf;
         ld_in = nh;
@@ -335,16 +365,7 @@ int forward_rows(xvec_handle* h, const float* x_rows, int ldx, const int64_t* of
     }
     {
         StageTimer t(h, T_POOL, s);
-        PoolFinalizeArgs f;
-        f.part = part;
-        f.out = pooled;
-        f.map = map;
-        f.C = XVEC_POOL_CHANNELS;
-        f.n_pad = h->geo[4].n_pad;
-        f.sub_rows = 32;
-        f.scale = h->vec[4] + f.n_pad;              // the pooling epilogues leave sums of r = relu(z + bias)
-        f.shift = h->vec[4] + 2 * f.n_pad;
-        HIP_TRY(launch_pool_finalize(f, s));
+        if ((rc = finalize_pool(h, part, part_cnt, map, pooled, s))) return rc;
     }
     if (mode == XVEC_MODE_POOLED) return XVEC_OK;
     const int xv = h->cfg.x_vector_size, K6 = 2 * XVEC_POOL_CHANNELS;
@@ -723,20 +744,11 @@ int xvec_tdnn_pool_layer(xvec_handle* h, const float* x, int32_t B, int32_t T, i
     map.fixed_T = T;
     map.cum = g.ctx_span;
     float* part = reinterpret_cast<float*>(ws + p.part);
+    int* part_cnt = reinterpret_cast<int*>(ws + p.part_cnt);
     int rc = run_tdnn(h, layer, in16 ? TdnnVariant::kBf16Pool : TdnnVariant::kF32Pool, xin, ldx, 0, nullptr,
-                      (int64_t)B * (T - g.ctx_span), map, part, s, x3, x_plane, 0);
+                      (int64_t)B * (T - g.ctx_span), map, part, s, x3, x_plane, 0, part_cnt);
     if (rc) return rc;
-    PoolFinalizeArgs f;
-    f.part = part;
-    f.out = out;
-    f.map = map;
-    f.C = XVEC_POOL_CHANNELS;
-    f.n_pad = g.n_pad;
-    f.sub_rows = 32;
-    f.scale = h->vec[layer] + f.n_pad;
-    f.shift = h->vec[layer] + 2 * f.n_pad;
-    HIP_TRY(launch_pool_finalize(f, s));
-    return XVEC_OK;
+    return finalize_pool(h, part, part_cnt, map, out, s);
 }
 
 int xvec_stat_pool(const float* x, const int32_t* lengths_dev, int32_t B, int32_t T, int32_t C, float* out,

@@ -100,6 +100,8 @@ struct TdnnArgs {
     int span;                 // frames this layer consumes (c[-1]-c[0]): input row = p + u(p)*span
     // fused statistics-pooling epilogue (layer 5)
     float* pool_part;         // [slots][3][n_pad]: pivot K | sum (r-K) | sum (r-K)^2, r = relu(z + bias), per (32-row group, utterance)
+                              // (tdnn_pp16.hip: per (block of the column, utterance, frames half) -- see there)
+    int* pool_cnt;            // tdnn_pp16.hip only: frames behind each of its partials, [slots]
     // bf16x3 (fp32 values carried as two bf16 planes hi + lo, three bf16 products per k-step:
     // x_hi*W_hi + x_hi*W_lo + x_lo*W_hi).  terms == 2: X has a lo plane x_plane_bytes after the hi
     // plane and Wf holds, per chunk, the W_hi fragments followed by the W_lo fragments.
@@ -146,6 +148,10 @@ hipError_t launch_stat_pool(const PoolArgs& a, hipStream_t s);
 
 struct PoolFinalizeArgs {
     const float* part;       // [slots][3][n_pad]: pivot K | sum (r-K) | sum (r-K)^2 of r = relu(z + bias) per (sub-tile, utterance)
+    // segment form (partials of tdnn_pp16.hip: one per (block of the column, utterance, frames half), slot 2 (b + u) + g):
+    const int* cnt;          // frames behind each partial, or nullptr for the sub-tile form
+    int64_t units_total;     // 64-frame units of the layer's output and blocks per column of the launch that wrote the
+    int blocks_per_col;      // partials: block b owns units [units_total b / blocks_per_col, units_total (b+1) / blocks_per_col)
     float* out;              // [B][2C]
     RowMap map;              // row layout of the pooled activation (layer 5 output)
     int C, n_pad, sub_rows;

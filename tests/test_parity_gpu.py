@@ -307,7 +307,7 @@ def test_extreme_shapes(sd42, synth, precision, tol):
     # the same utterance at another place in the batch: equal to fp32 rounding, not bit for bit -- the fused pooling
     # sums deviations from a pivot (the first frame of the 32-row group the rows fall in, csrc/tdnn_common.h), which
     # depends on the position; repeat runs of the same batch ARE bit-identical (test_full_size_properties)
-    assert_parity(outb[5:10], outb[n_big - 5:n_big], 1e-6, "same utterances, other batch position")
+    assert_parity(outb[5:10], outb[n_big - 5:n_big], 1e-5, "same utterances, other batch position")
     # one utterance more than a library call takes: the host module makes two calls of it (round 1 raised here);
     # the C entry point itself still refuses
     over = torch.cat([big, big[:1]], 0) if n_big == 65535 else big

@@ -165,8 +165,8 @@ __device__ __forceinline__ int64_t pool_first_row(const RowMap& m, int u) {
 // of the std at mean/std = 40, an always-on low-variance post-ReLU channel (VERDICT r02 / ADVICE r02).  About a
 // sample of the same channel the sums are of deviations: the loss is ~1e-7*(1 + ((mean - K)/std)^2), and K is
 // within a few std of the mean.  A group that straddles utterances uses the one pivot for all of them (a
-// neighbouring utterance's frame of the same channel).  Cost: one permlane swap per accumulator and half a
-// v_pk_add_f32 per value.
+// neighbouring utterance's frame of the same channel).  Cost: one permlane swap per accumulator and one v_sub_f32
+// per value.
 template <bool RAGGED>
 __device__ __forceinline__ void pool_group_impl(const TdnnArgs& a, const f32x16& v, int64_t row_g, int h, int col,
                                                 PoolCur& pc) {
@@ -178,16 +178,19 @@ __device__ __forceinline__ void pool_group_impl(const TdnnArgs& a, const f32x16&
         pc.end = pool_first_row<RAGGED>(m, pc.u + 1);
     }
     const float K = lower_half(v[0]);
-    if (pc.end >= row_g + 32) {               // whole group inside utterance pc.u: no masks, two values per instruction
-        const f32x2 kk = {K, K};
-        f32x2 p1 = {0.f, 0.f}, p2 = {0.f, 0.f};
+    if (pc.end >= row_g + 32) {               // whole group inside utterance pc.u: no masks
+        // plain v_sub / v_add / v_fma in four interleaved chains: v_pk_add_f32 / v_pk_fma_f32, which round 2 used here
+        // ("two values per instruction"), issue at ~17 cycles each (MI355X_MICROARCH.md, price of fillers beside
+        // MFMAs) -- twice the cost of the two scalar instructions they replace, in an epilogue that only issues in the
+        // gaps of the partner wave's MFMA stream
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
 #pragma unroll
-        for (int e = 0; e < 16; e += 2) {
-            const f32x2 d = f32x2{v[e], v[e + 1]} - kk;
-            p1 += d;
-            p2 = __builtin_elementwise_fma(d, d, p2);
+        for (int e = 0; e < 16; e += 4) {
+            const float d0 = v[e] - K, d1 = v[e + 1] - K, d2 = v[e + 2] - K, d3 = v[e + 3] - K;
+            a0 += d0; a1 += d1; a2 += d2; a3 += d3;
+            b0 = fmaf(d0, d0, b0); b1 = fmaf(d1, d1, b1); b2 = fmaf(d2, d2, b2); b3 = fmaf(d3, d3, b3);
         }
-        const float s1 = add_halves(p1.x + p1.y), s2 = add_halves(p2.x + p2.y);
+        const float s1 = add_halves((a0 + a1) + (a2 + a3)), s2 = add_halves((b0 + b1) + (b2 + b3));
         store_partial(prs, a.ldy, grp + pc.u, h, col, K, s1, s2);
         return;
     }

@@ -528,12 +528,13 @@ struct Seg {
 // quad 0 writes the pivots (16 bytes per lane); one lane of the block's first column writes the frame count.
 __device__ __forceinline__ void flush_seg(const TdnnArgs& a, Seg& sg, int slot, int n_rows, int q, int col0, bool cnt_writer) {
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-    const __amdgpu_buffer_rsrc_t prs = make_rsrc(a.pool_part);
     const int ld = a.ldy;
+    // descriptor at the slot (64-bit base: no 2 GiB limit on the partials buffer; a flush is rare)
+    const __amdgpu_buffer_rsrc_t prs = make_rsrc(a.pool_part + (int64_t)slot * (kPoolPlanes * ld));
     const float y0 = swap32_add(sg.s1[0], sg.s1[2]), y1 = swap32_add(sg.s2[0], sg.s2[2]);
     const float y2 = swap32_add(sg.s1[1], sg.s1[3]), y3 = swap32_add(sg.s2[1], sg.s2[3]);
     const float z0 = swap16_add(y0, y1), z1 = swap16_add(y2, y3);
-    const int soff = slot * kPoolPlanes * ld * 4;
+    const int soff = 0;
     const u32x2 v = {__float_as_uint(z0), __float_as_uint(z1)};
     __builtin_amdgcn_raw_buffer_store_b64(v, prs, (col0 + (q >> 1) * 2 + (1 + (q & 1)) * ld) * 4, soff, 0);
     if (q == 0) {

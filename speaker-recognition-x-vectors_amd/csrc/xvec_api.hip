@@ -269,6 +269,10 @@ int run_tdnn(xvec_handle* h, int layer, TdnnVariant v, const void* X, int ldx, i
         h->last_kernel[layer] = XVEC_KERNEL_FIRST;
         return XVEC_OK;
     }
+    // pooling partials of the 128x128 kernels: one slot per (32-row group, utterance), addressed with 32-bit offsets
+    // (tdnn_pp16.hip's segment partials take a 64-bit base per slot and have no such limit)
+    if (part && (size_t)((rows_out + 31) / 32 + out_map.n_utts + 1) * 3 * g.n_pad * 4 > 0x7fffffffull)
+        return fail(XVEC_ERR_ARG, "batch too large: pooling partials exceed 2 GiB; split it");
     HIP_TRY(launch_tdnn(a, v, s));
     h->last_kernel[layer] = XVEC_KERNEL_TILE128;
     return XVEC_OK;
@@ -349,8 +353,6 @@ int forward_rows(xvec_handle* h, const float* x_rows, int ldx, const int64_t* of
         HIP_TRY(launch_pack_rows_split(x_rows, p.total, ldx, ldx, in_plane / 2, x16, s));
         in = x16;
     }
-    if ((size_t)p.part_slots * 3 * h->geo[4].n_pad * 4 > 0x7fffffffull)
-        return fail(XVEC_ERR_ARG, "batch too large: pooling partials exceed 2 GiB; split it");
     for (int l = 0; l < XVEC_NUM_TDNN; ++l) {
         map.cum += h->geo[l].ctx_span;
         const int64_t rows_out = p.total - (int64_t)B * map.cum;
@@ -721,8 +723,6 @@ int xvec_tdnn_pool_layer(xvec_handle* h, const float* x, int32_t B, int32_t T, i
     const Plan p = make_plan(h, (int64_t)B * T, B);
     if (workspace_bytes < p.bytes)
         return fail(XVEC_ERR_WORKSPACE, "workspace too small: %zu < %zu", workspace_bytes, p.bytes);
-    if ((size_t)p.part_slots * 3 * g.n_pad * 4 > 0x7fffffffull)
-        return fail(XVEC_ERR_ARG, "batch too large: pooling partials exceed 2 GiB; split it");
     hipStream_t s = static_cast<hipStream_t>(stream);
     char* ws = static_cast<char*>(workspace);
     const bool x3 = dtype == XVEC_BF16X3, in16 = x3 || dtype == XVEC_BF16;

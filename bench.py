@@ -434,11 +434,11 @@ def main():
         # bf16x3 spends three bf16 MFMAs per algorithmic product: its roof is a third of the bf16 peak
         peak = {"fp32": FP32_MFMA_PEAK, "bf16": BF16_MFMA_PEAK, "bf16x3": BF16_MFMA_PEAK / 3}[args.dtype]
         # which kernel layers 2-4 actually went to, as the library reports it (xvec_get_dispatch): bf16 at this batch
-        # size runs the 256-channel ping-pong mapping (csrc/tdnn_pp.hip); smaller batches, other CU counts, XVEC_PP=0
+        # size runs the 256-channel ping-pong mapping (csrc/tdnn_pp16.hip); smaller batches, other CU counts, XVEC_PP=0
         # and bf16x3 the 128x128 kernel (csrc/tdnn_layer.hip)
         disp = model.last_dispatch(dev)
         pp16 = disp[1:4] == ["pp", "pp", "pp"]
-        dom_kernel = ("xvec::pp::tdnn_pp_kernel<false> (layers 2-4, bf16 MFMA, LDS-DMA operands)" if pp16 else
+        dom_kernel = ("xvec::pp16::tdnn_pp_kernel<false> (layers 2-4, v_mfma_f32_16x16x32_bf16, LDS-DMA operands)" if pp16 else
                       "xvec::tdnn_kernel<0,false,true,true,true,X3> (layers 2-4, bf16 MFMA"
                       + (", three products per k-step)" if args.dtype == "bf16x3" else ")") if bf else
                       "xvec::tdnn_kernel<0,false,true,false,false,false> (layers 2-4, fp32 MFMA)")
@@ -451,7 +451,7 @@ def main():
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
             tj = tj[args.dtype]                             # one section per arithmetic
             key = {"fp32": "tdnn_kernel<0, false, true, false, false, false>",
-                   "bf16": "pp::tdnn_pp_kernel<false>" if pp16 else "tdnn_kernel<0, false, true, true, true, false>",
+                   "bf16": "pp16::tdnn_pp_kernel<false>" if pp16 else "tdnn_kernel<0, false, true, true, true, false>",
                    "bf16x3": "tdnn_kernel<0, false, true, true, true, true>"}[args.dtype]
             traffic, traffic_src = tj[key]["hbm_bytes_per_launch"], tj["source"]
         except (OSError, KeyError, ValueError, StopIteration):

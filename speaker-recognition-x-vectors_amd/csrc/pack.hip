@@ -95,12 +95,12 @@ hipError_t launch_pack_tdnn_bf16(const float* W, const TdnnGeom& geo, void* Wf16
     return hipGetLastError();
 }
 
-// bf16 weights for tdnn_pp.hip, K-TILE major: [256-channel column block][K-tile of 64][256 rows][64 k]
+// bf16 weights for tdnn_pp16.hip, K-TILE major: [256-channel column block][K-tile of 64][256 rows][64 k]
 // (K order as everywhere: 64-element chunks, taps innermost).  Both operands of that kernel reach LDS by
 // DMA in 128-byte row slabs; a K-tile of a column block is then one contiguous 32 KiB, so the 256 CUs
 // that fetch the same tile at the same time spread over all L2 channels (128-byte slabs of plain rows,
 // 1-3 KiB apart, fall on two of them).
-__global__ void pack_tdnn_weight_ktile_kernel(const float* __restrict__ W, TdnnGeom g, int shape, __bf16* __restrict__ Wt) {
+__global__ void pack_tdnn_weight_ktile_kernel(const float* __restrict__ W, TdnnGeom g, __bf16* __restrict__ Wt) {
     const int64_t total = (int64_t)g.n_pad * g.k_pad;
     const int nk = g.k_pad / 64;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
@@ -108,12 +108,9 @@ __global__ void pack_tdnn_weight_ktile_kernel(const float* __restrict__ W, TdnnG
         const int w = (int)(i & 63), r = (int)((i >> 6) & 255);
         const int64_t t = i >> 14;                       // (column block, K-tile)
         const int cb = (int)(t / nk), q = (int)(t % nk);
-        // row r of a column block holds channel 64*wc + 2*l + j (wc = r >> 6, j = (r >> 5) & 1, l = r & 31): lane l of
-        // a wave's two accumulators then owns the ADJACENT channels 2l, 2l+1 of its 64-channel block, and the
-        // epilogues write them as one dword / one pair (tdnn_pp.hip)
-        // shape 16 (tdnn_pp16.hip, 16x16x32 MFMAs): row 16*b + c of a wave's 64 rows holds channel 4*c + b, so lane c's
-        // four accumulators of a frame own FOUR adjacent channels
-        const int n = cb * 256 + (r & ~63) + (shape == 16 ? 4 * (r & 15) + ((r >> 4) & 3) : 2 * (r & 31) + ((r >> 5) & 1));
+        // row 16*b + c of a wave's 64 rows (wave wc = r >> 6) holds channel 64*wc + 4*c + b: lane c's four 16x16 accumulators
+        // of a frame then own FOUR adjacent channels, which the epilogues of tdnn_pp16.hip write as one 8-byte piece
+        const int n = cb * 256 + (r & ~63) + 4 * (r & 15) + ((r >> 4) & 3);
         const int kd = tap_major_k(g, q * 64 + w);
         const int tap = kd / g.tap_stride_src, c = kd % g.tap_stride_src;
         float v = 0.f;
@@ -122,9 +119,9 @@ __global__ void pack_tdnn_weight_ktile_kernel(const float* __restrict__ W, TdnnG
         Wt[i] = (__bf16)v;
     }
 }
-hipError_t launch_pack_tdnn_rows_bf16(const float* W, const TdnnGeom& geo, void* Wr16, int shape, hipStream_t s) {
-    if (geo.n_pad % 256 != 0) return hipSuccess;        // tdnn_pp.hip is not used for such a layer
-    pack_tdnn_weight_ktile_kernel<<<1024, 256, 0, s>>>(W, geo, shape, static_cast<__bf16*>(Wr16));
+hipError_t launch_pack_tdnn_rows_bf16(const float* W, const TdnnGeom& geo, void* Wr16, hipStream_t s) {
+    if (geo.n_pad % 256 != 0) return hipSuccess;        // tdnn_pp16.hip is not used for such a layer
+    pack_tdnn_weight_ktile_kernel<<<1024, 256, 0, s>>>(W, geo, static_cast<__bf16*>(Wr16));
     return hipGetLastError();
 }
 

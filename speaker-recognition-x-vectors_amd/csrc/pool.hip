@@ -5,7 +5,7 @@
 //                            the utterance as a shift (sums of (x-K), (x-K)^2 are well
 //                            conditioned since K is a sample of the same distribution).
 //  * pool_finalize_kernel -- merges the per-sub-tile pivoted partials that the layer-5
-//                            epilogues (tdnn_layer.hip, tdnn_pp.hip) write, in fp64.
+//                            epilogues (tdnn_layer.hip) write, in fp64; pool_finalize_seg_kernel the segment partials of tdnn_pp16.hip.
 //
 // n == 1 gives NaN std exactly like torch.std (0/0); the caller rejects n < 1.
 #include "xvec_internal.h"
@@ -109,7 +109,7 @@ hipError_t launch_stat_pool(const PoolArgs& a, hipStream_t s) {
 
 // One thread per (utterance, channel): merge the partials (K, S1, S2) -- pivot, sum (r - K), sum (r - K)^2 over the
 // utterance's n_g frames in the sub-tile, r = relu(z + bias) -- that the layer-5 epilogues (tdnn_layer.hip,
-// tdnn_pp.hip) wrote per (32-row sub-tile, utterance), then apply the folded BatchNorm y = scale*r + shift.
+// bf16x3 and small-batch bf16 included) wrote per (32-row sub-tile, utterance), then apply the folded BatchNorm y = scale*r + shift.
 // Every sub-tile's sums are re-based to the pivot K0 of the utterance's first sub-tile in fp64
 // (d = K - K0:  S1' = S1 + n_g*d,  S2' = S2 + 2*d*S1 + n_g*d^2: multiply-adds only), so
 //   mean = shift + scale*(K0 + S1'/n),   std = |scale| * sqrt((S2' - S1'^2/n) / (n-1))

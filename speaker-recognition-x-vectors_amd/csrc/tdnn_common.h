@@ -137,7 +137,7 @@ struct PoolCur {
 // Row offset of a ragged batch through the SCALAR cache.  hipcc loads `offsets[u]` with a vector load even
 // for a provably uniform u (the pointer is not known to be read-only), and the s_waitcnt vmcnt(0) it puts
 // behind that load drains every vector-memory operation the wave has in flight (the staging loads of the
-// K loop, the LDS-DMA queue of tdnn_pp.hip); the array is written by the host before the launch.
+// K loop, the LDS-DMA queue of tdnn_pp16.hip); the array is written by the host before the launch.
 __device__ __forceinline__ int64_t sload_i64(const int64_t* p) {
     int64_t v;
     asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");

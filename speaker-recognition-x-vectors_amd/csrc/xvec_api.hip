@@ -67,9 +67,8 @@ struct xvec_handle {
     TdnnGeom geo[XVEC_NUM_TDNN];
     TdnnGeom geo16[XVEC_NUM_TDNN];     // bf16 packing of layers 2-5: 64-element chunks (layer 1 stays fp32)
     void* Wp16[XVEC_NUM_TDNN];         // bf16, fragment-major
-    void* Wr16[XVEC_NUM_TDNN];         // bf16, row-major [n_pad][k_pad] (tdnn_pp.hip: both operands reach LDS by DMA)
+    void* Wr16[XVEC_NUM_TDNN];         // bf16, K-tile major [n_pad/256][k_pad/64][256][64] (tdnn_pp16.hip: both operands reach LDS by DMA)
     bool use_pp;                       // large-batch bf16 mapping enabled (XVEC_PP=0 disables it: A/B runs)
-    int pp_shape;                      // its MFMA shape: 16 (v_mfma_f32_16x16x32_bf16, tdnn_pp16.hip) or 32 (XVEC_PP_SHAPE=32: tdnn_pp.hip)
     void* Wp48[XVEC_NUM_TDNN];         // bf16x3: per chunk W_hi then W_lo fragments (2x the size), fragment-major
     float* Wp[XVEC_NUM_TDNN];
     float* vec[XVEC_NUM_TDNN];         // bias | scale | shift, n_pad each
@@ -244,7 +243,7 @@ int run_tdnn(xvec_handle* h, int layer, TdnnVariant v, const void* X, int ldx, i
     }
     StageTimer t(h, T_L1 + layer, s);
     // bf16, wide layers, enough rows to give every CU a little over two 64-frame units: the 256-channel
-    // ping-pong mapping (tdnn_pp.hip); everything else (small batches, layer 1, narrow models, fp32,
+    // ping-pong mapping (tdnn_pp16.hip); everything else (small batches, layer 1, narrow models, fp32,
     // bf16x3) runs the 128x128 kernel
     if (h->use_pp && !x3 && layer > 0 && (v == TdnnVariant::kBf16 || v == TdnnVariant::kBf16Pool) && g.n_pad % 256 == 0) {
         const int n_cols = g.n_pad / 256;
@@ -258,8 +257,7 @@ int run_tdnn(xvec_handle* h, int layer, TdnnVariant v, const void* X, int ldx, i
             a.pair_period = 0;
             h->pool_units = units;
             h->pool_bpc = bpc;
-            if (h->pp_shape == 16) HIP_TRY(launch_tdnn_pp16(a, v == TdnnVariant::kBf16Pool, s));
-            else HIP_TRY(launch_tdnn_pp(a, v == TdnnVariant::kBf16Pool, s));
+            HIP_TRY(launch_tdnn_pp16(a, v == TdnnVariant::kBf16Pool, s));
             h->last_kernel[layer] = XVEC_KERNEL_PP;
             return XVEC_OK;
         }
@@ -301,7 +299,7 @@ int finalize_pool(xvec_handle* h, const float* part, const int* part_cnt, const 
     f.sub_rows = 32;
     f.scale = h->vec[4] + f.n_pad;              // the pooling epilogues leave sums of r = relu(z + bias)
     f.shift = h->vec[4] + 2 * f.n_pad;
-    if (h->last_kernel[4] == XVEC_KERNEL_PP && h->pp_shape == 16) {     // tdnn_pp16.hip: one partial per (block, utterance, half)
+    if (h->last_kernel[4] == XVEC_KERNEL_PP) {     // tdnn_pp16.hip: one partial per (block, utterance, half)
         f.cnt = part_cnt;
         f.units_total = h->pool_units;
         f.blocks_per_col = h->pool_bpc;
@@ -467,8 +465,6 @@ int xvec_create(const xvec_cfg* cfg, xvec_handle** out) {
         if (h->blocks_per_cu < 1) h->blocks_per_cu = 1;
         const char* p = getenv("XVEC_PP");
         h->use_pp = !(p && atoi(p) == 0);
-        const char* sh = getenv("XVEC_PP_SHAPE");
-        h->pp_shape = (sh && atoi(sh) == 32) ? 32 : 16;
     }
     h->cin_pad = round_up(cfg->input_size, 4);
     fill_geometry(h, h->geo, 2 * kBK);
@@ -550,7 +546,7 @@ int xvec_load_tdnn(xvec_handle* h, int layer, const float* weight, const float* 
                              h->vec[layer], h->vec[layer] + g.n_pad, h->vec[layer] + 2 * g.n_pad,
                              static_cast<hipStream_t>(stream)));
     HIP_TRY(launch_pack_tdnn_bf16(weight, h->geo16[layer], h->Wp16[layer], static_cast<hipStream_t>(stream)));
-    HIP_TRY(launch_pack_tdnn_rows_bf16(weight, h->geo16[layer], h->Wr16[layer], h->pp_shape, static_cast<hipStream_t>(stream)));
+    HIP_TRY(launch_pack_tdnn_rows_bf16(weight, h->geo16[layer], h->Wr16[layer], static_cast<hipStream_t>(stream)));
     {
         TdnnGeom g3 = h->geo16[layer];
         g3.terms = 2;

@@ -7,7 +7,7 @@
 namespace xvec {
 
 constexpr int kBK = 32;          // K-chunk (fp32 elements) staged per main-loop step
-constexpr int kRowPadTail = 264; // readable rows past M_pad: a masked tile of tdnn_pp.hip may reach two 64-row units (+63 of
+constexpr int kRowPadTail = 264; // readable rows past M_pad: a masked tile of tdnn_pp16.hip may reach two 64-row units (+63 of
                                  // rounding) past the last valid row, + max tap reach (6); tdnn_layer.hip's look-ahead needs 134
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
@@ -124,19 +124,16 @@ enum class TdnnVariant {
     kBf16FirstToF32   // layer 1, guarded, bf16 -> fp32 (per-layer test entry in bf16x3)
 };
 hipError_t launch_tdnn(const TdnnArgs& a, TdnnVariant v, hipStream_t s);
-// Large-batch bf16 mapping (tdnn_pp.hip): 256-channel columns, 64-frame units.  Reads TdnnArgs with
+// Large-batch bf16 mapping (tdnn_pp16.hip, v_mfma_f32_16x16x32_bf16): 256-channel columns, 64-frame units.  Reads TdnnArgs with
 //   W = K-tile major bf16 [n_pad/256][k_pad/64][256][64] (K order as the fp32 packing, 64-element chunks), n_tiles = n_pad / 256,
 //   groups_total = ceil(rows / 64) units, blocks_per_col ranges per column (>= 2.2 units each for full speed).
-hipError_t launch_tdnn_pp(const TdnnArgs& a, bool pool, hipStream_t s);
-// the same mapping on v_mfma_f32_16x16x32_bf16 (tdnn_pp16.hip); W packed with shape 16 (pack.hip)
 hipError_t launch_tdnn_pp16(const TdnnArgs& a, bool pool, hipStream_t s);
 // Layer 1 of the bf16 path as a streaming kernel (tdnn_first.hip): weights resident in registers, 16-byte stores.
 // Reads TdnnArgs as the 128x128 kernel does (Wf = fragment-major bf16 weights); X holds the caller's fp32 rows.
 bool tdnn_first_applicable(const TdnnArgs& a);
 hipError_t launch_tdnn_first(const TdnnArgs& a, int num_cu, hipStream_t s);
-// K-tile major bf16 copy of the packed weights for it; shape = 32 (tdnn_pp.hip) or 16 (tdnn_pp16.hip): the row order inside
-// a wave's 64-channel block
-hipError_t launch_pack_tdnn_rows_bf16(const float* W, const TdnnGeom& geo, void* Wr16, int shape, hipStream_t s);
+// K-tile major bf16 copy of the packed weights for it
+hipError_t launch_pack_tdnn_rows_bf16(const float* W, const TdnnGeom& geo, void* Wr16, hipStream_t s);
 
 struct PoolArgs {
     const float* X;          // [B][T][C]

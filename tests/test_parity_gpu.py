@@ -298,7 +298,7 @@ def test_extreme_shapes(sd42, synth, precision, tol):
     assert n_big == 65535 or precision == "bf16x3"
     outb = m.extract_x_vec(big)
     alone = m.extract_x_vec(big[:5])
-    # bf16: the large batch runs the 256-channel mapping (tdnn_pp.hip: bias in the accumulator's start value,
+    # bf16: the large batch runs the 256-channel mapping (tdnn_pp16.hip: bias in the accumulator's start value,
     # raw-sum pooling), five utterances run the 128x128 kernel -- same arithmetic type, different rounding
     # order (measured 3e-5; either is 9e-4 from fp32).  fp32 / bf16x3 have one kernel: bit-level agreement.
     same = 2e-4 if precision == "bf16" else 1e-5

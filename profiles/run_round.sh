@@ -2,18 +2,26 @@
 # Round profile set (run on the GPU box via gpurun):  bash profiles/run_round.sh <tag>
 #   kernel-trace stats of the default bench line (fp32 + its secondary legs), of --dtype bf16 and of --dtype bf16x3,
 #   FETCH_SIZE / WRITE_SIZE passes for both, utilisation counters for both.  Output: gpurun_out/<tag>/
-tag=${1:-r02}
+tag=${1:-r03}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/$tag
 mkdir -p $out
+if [ -z "$ONLY_PMC" ]; then
 python3 bench.py --steps 50 --warmup 10 > $out/bench_fp32.json 2> $out/bench_fp32.err; echo "bench fp32 exit $?"
 python3 bench.py --steps 50 --warmup 10 --dtype bf16 --cpu-budget 0 > $out/bench_bf16.json 2> $out/bench_bf16.err; echo "bench bf16 exit $?"
 python3 bench.py --steps 20 --warmup 5 --workload ragged --cpu-budget 0 > $out/bench_ragged.json 2> $out/bench_ragged.err; echo "bench ragged exit $?"
 python3 bench.py --steps 20 --warmup 5 --workload ragged --dtype bf16 --cpu-budget 0 > $out/bench_ragged_bf16.json 2> $out/bench_ragged_bf16.err; echo "bench ragged bf16 exit $?"
 python3 bench.py --steps 50 --warmup 10 --dtype bf16x3 --cpu-budget 0 > $out/bench_bf16x3.json 2> $out/bench_bf16x3.err; echo "bench bf16x3 exit $?"
+python3 bench.py --steps 20 --warmup 5 --preroll 0 --cpu-budget 0 --no-secondary > $out/bench_fp32_preroll0.json 2> $out/bench_fp32_preroll0.err; echo "bench fp32 --preroll 0 (round-1 protocol) exit $?"
+python3 bench.py --workload job --utterances 20000 --cpu-budget 0 > $out/bench_job20k.json 2> $out/bench_job20k.err; echo "bench job exit $?"
+python3 bench.py --workload job --utterances 20000 --dtype bf16 --cpu-budget 0 > $out/bench_job20k_bf16.json 2> $out/bench_job20k_bf16.err; echo "bench job bf16 exit $?"
+python3 bench.py --steps 20 --warmup 5 --workload wave --cpu-budget 0 > $out/bench_wave.json 2> $out/bench_wave.err; echo "bench wave exit $?"
+python3 bench.py --gpus 1 --force-collective --steps 20 --warmup 5 --cpu-budget 0 > $out/bench_collective1.json 2> $out/bench_collective1.err; echo "bench one-rank RCCL exit $?"
+fi
 for dt in fp32 bf16 bf16x3; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_$dt -o $dt -- python3 bench.py --steps 20 --warmup 5 --cpu-budget 0 --no-secondary --dtype $dt > $out/stats_$dt.log 2>&1
+  mkdir -p $out/pmc_$dt
+  [ -z "$ONLY_PMC" ] && rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_$dt -o $dt -- python3 bench.py --steps 20 --warmup 5 --cpu-budget 0 --no-secondary --dtype $dt > $out/stats_$dt.log 2>&1
   echo "stats $dt exit $?"
   i=0
   for grp in "FETCH_SIZE" "WRITE_SIZE" \

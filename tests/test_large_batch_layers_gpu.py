@@ -208,3 +208,24 @@ def test_bf16_bench_batch_sampled_rows_vs_oracle(sd42, synth, models):
     with torch.no_grad():
         refl = oracle.forward(torch.from_numpy(x[idx]), float_params(sd42))
     assert_parity(logits[idx], refl, 1e-2, "bf16 B=256 sampled logits vs oracle")
+
+
+# ------------------------------------------------------------------ the fp32 headline at its own size
+def test_fp32_every_layer_every_element_at_the_bench_size(gpu_model, sd42, synth):
+    """BASELINE configs[1] at its own size (B = 256, T = 300): every element of every fp32 layer against the fp64 oracle
+    at the path's bar (1e-4), layer 5 + fused pooling of every utterance (means and stds separately), repeat runs
+    bit-identical.  (The small-size whole-tensor tests of test_parity_gpu.py cover tile edges; this one the persistent
+    grid at full occupancy: 512 blocks, CU-pair-aware row ranges.)"""
+    p64 = oracle.cast_params(float_params(sd42), torch.float64)
+    h = torch.as_tensor(synth.make_mfcc(256, 300, seed=4256)).to(DEV)
+    for i in range(5):
+        got = gpu_model.time_context_layers[i](h)
+        assert gpu_model.last_dispatch()[i] == "tile128"
+        assert torch.equal(got, gpu_model.time_context_layers[i](h)), f"layer {i}: repeat run differs"
+        assert_parity(got, _oracle_layer(h.cpu(), p64, i), 1e-4, f"fp32 layer {i} B=256 vs oracle")
+        if i == 3:
+            pooled = gpu_model.pooled_last_layer(got)
+            ref = oracle.stat_pool(_oracle_layer(got.cpu(), p64, 4).double())
+            assert_parity(pooled[:, :1500], ref[:, :1500], 1e-4, "fp32 pooled means, B=256")
+            assert_parity(pooled[:, 1500:], ref[:, 1500:], 1e-4, "fp32 pooled stds, B=256")
+        h = got

@@ -69,6 +69,7 @@ struct xvec_handle {
     void* Wp16[XVEC_NUM_TDNN];         // bf16, fragment-major
     void* Wr16[XVEC_NUM_TDNN];         // bf16, K-tile major [n_pad/256][k_pad/64][256][64] (tdnn_pp16.hip: both operands reach LDS by DMA)
     bool use_pp;                       // large-batch bf16 mapping enabled (XVEC_PP=0 disables it: A/B runs)
+    int pp_min_tenths;                 // ... from this many tenths of a 64-frame unit per CU on (18; XVEC_PP_MIN_TENTHS: crossover sweeps)
     void* Wp48[XVEC_NUM_TDNN];         // bf16x3: per chunk W_hi then W_lo fragments (2x the size), fragment-major
     float* Wp[XVEC_NUM_TDNN];
     float* vec[XVEC_NUM_TDNN];         // bias | scale | shift, n_pad each
@@ -242,14 +243,14 @@ int run_tdnn(xvec_handle* h, int layer, TdnnVariant v, const void* X, int ldx, i
         a.x_bytes = x_rows > 0 ? x_plane + x_rows * (int64_t)ldx * 2 : 0;
     }
     StageTimer t(h, T_L1 + layer, s);
-    // bf16, wide layers, enough rows to give every CU a little over two 64-frame units: the 256-channel
+    // bf16, wide layers, enough rows to give every CU about two 64-frame units: the 256-channel
     // ping-pong mapping (tdnn_pp16.hip); everything else (small batches, layer 1, narrow models, fp32,
     // bf16x3) runs the 128x128 kernel
     if (h->use_pp && !x3 && layer > 0 && (v == TdnnVariant::kBf16 || v == TdnnVariant::kBf16Pool) && g.n_pad % 256 == 0) {
         const int n_cols = g.n_pad / 256;
         const int bpc = h->num_cu / n_cols;
         const int64_t units = (rows_out + 63) / 64;
-        if (bpc >= 1 && 5 * units >= 11 * (int64_t)bpc) {          // >= 2.2 units per CU (measured crossover, T = 300: 62 utterances)
+        if (bpc >= 1 && units >= bpc && 10 * units >= h->pp_min_tenths * (int64_t)bpc) {   // >= 1.8 units per CU (measured crossover of layers 2-4, round 3: 51 utterances of 300 frames; layer 5: 18)
             a.W = h->Wr16[layer];
             a.n_tiles = n_cols;
             a.blocks_per_col = bpc;
@@ -465,6 +466,8 @@ int xvec_create(const xvec_cfg* cfg, xvec_handle** out) {
         if (h->blocks_per_cu < 1) h->blocks_per_cu = 1;
         const char* p = getenv("XVEC_PP");
         h->use_pp = !(p && atoi(p) == 0);
+        const char* mt = getenv("XVEC_PP_MIN_TENTHS");
+        h->pp_min_tenths = mt && atoi(mt) > 0 ? atoi(mt) : 18;
     }
     h->cin_pad = round_up(cfg->input_size, 4);
     fill_geometry(h, h->geo, 2 * kBK);

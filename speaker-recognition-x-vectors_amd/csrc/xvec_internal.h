@@ -126,7 +126,7 @@ enum class TdnnVariant {
 hipError_t launch_tdnn(const TdnnArgs& a, TdnnVariant v, hipStream_t s);
 // Large-batch bf16 mapping (tdnn_pp16.hip, v_mfma_f32_16x16x32_bf16): 256-channel columns, 64-frame units.  Reads TdnnArgs with
 //   W = K-tile major bf16 [n_pad/256][k_pad/64][256][64] (K order as the fp32 packing, 64-element chunks), n_tiles = n_pad / 256,
-//   groups_total = ceil(rows / 64) units, blocks_per_col ranges per column (>= 2.2 units each for full speed).
+//   groups_total = ceil(rows / 64) units, blocks_per_col ranges per column (>= 1.8 units each: the measured crossover with the 128x128 kernel).
 hipError_t launch_tdnn_pp16(const TdnnArgs& a, bool pool, hipStream_t s);
 // Layer 1 of the bf16 path as a streaming kernel (tdnn_first.hip): weights resident in registers, 16-byte stores.
 // Reads TdnnArgs as the 128x128 kernel does (Wf = fragment-major bf16 weights); X holds the caller's fp32 rows.

@@ -6,7 +6,8 @@ output is compared at sizes that dispatch
   * `pp::tdnn_pp_kernel<false>` (tdnn_pp.hip, store variant: layers 2-4, and layer 5 through the per-layer entry),
   * `pp::tdnn_pp_kernel<true>` (layer 5 + fused pooling, through `xvec_tdnn_pool_layer`),
   * `first::tdnn_first_kernel` (tdnn_first.hip, layer 1 reading fp32 rows),
-with every tile height the persistent blocks cut: 63 utterances of 300 frames give blocks of 2 units of 64 frames,
+with every tile height the persistent blocks cut: 52 utterances of 300 frames (the smallest batch that dispatches them:
+1.8 units of 64 frames per CU) give blocks of 1 or 2 units (a 2-unit tile whose second unit is masked), 63 blocks of 2 or 3 units,
 100 -> 3 (+ masked last unit), 128 -> 5 = 3 + 2, 160 / 256 -> 4-unit tiles, (70, 517) boundaries inside tiles.
 
 Three references per layer, same input to all:
@@ -28,7 +29,7 @@ from conftest import assert_parity, float_params
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
-SHAPES = [(63, 300), (100, 300), (128, 300), (160, 300), (256, 300), (70, 517)]
+SHAPES = [(52, 300), (63, 300), (100, 300), (128, 300), (160, 300), (256, 300), (70, 517)]
 
 
 def _model(sd, precision, pp=True):

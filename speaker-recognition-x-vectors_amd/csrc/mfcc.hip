@@ -13,6 +13,7 @@
 // package's formulas (floor((nfft+1)*hz/samplerate) bin edges etc.) and kept on the device.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -35,6 +36,12 @@ struct MfccDev {
     int tw_off, dctl_off, fbw_off, fblo_off, fboff_off, table_floats;
     int frame_len, frame_step, nfft, log2n, nbins, nfilt, numcep, append_energy;
     float preemph;
+    // nfft == 512 kernel (fft512 below): per-lane twiddles, filterbank and DCT x lifter as MFMA B fragments
+    const float* f_tw1;     // [7][64] complex: W_512^(lane * k), k = 1..7
+    const float* f_tw2;     // [7][8] complex: W_64^(c * k)
+    const float* f_fb;      // [2 filter tiles][16 bin groups][64 lanes][4]
+    const float* f_dct;     // [2 cepstrum tiles][2 filter groups][64 lanes][4]
+    int f_n0, f_lo0, f_n1, f_lo1;   // bin groups with a non-zero weight: tile 0 [lo0, lo0+n0), tile 1 [lo1, lo1+n1)
 };
 
 __device__ __forceinline__ unsigned bitrev(unsigned v, int bits) { return __brev(v) >> (32 - bits); }
@@ -199,6 +206,275 @@ __global__ __launch_bounds__(kThreads) void mfcc_kernel(const float* __restrict_
     }
 }
 
+
+// ---- nfft == 512 (the reference's call, dataset.py:128) ------------------------------------------------------------
+// The kernel above walks the FFT through LDS one radix-4 pass at a time (five read-modify-write passes with a
+// wave-wide wait each) and gives the mel filters one LANE each (filter 25 walks 66 bins one LDS round trip at a
+// time): 118 us per 256 x 3 s, 26 k cycles per pair of frames, latency from end to end.  Here:
+//  * the 512-point FFT of a pair of frames is three radix-8 steps IN REGISTERS (8 complex points per lane:
+//    n = 64a + 8b + c, k = k0 + 8 k1 + 64 k2; DFT-8 over a, x W_512^((8b+c) k0), DFT-8 over b, x W_64^(c k1),
+//    DFT-8 over c) with two transposes through the wave's private LDS region between them (index maps chosen
+//    so that every ds_write_b64 / ds_read_b64 is conflict-free by the bank rules: rows of 8 padded to 9,
+//    planes of 64 padded to 72); the 14 twiddles of a lane never change and live in registers;
+//  * a block of four waves owns 16 consecutive frames of the batch (frames are numbered through the whole batch:
+//    76 544 = 4784 x 16 for 256 x 299, no ragged last tile per utterance), two pairs per wave, and leaves their
+//    power spectra in LDS as a [16][256] matrix;
+//  * mel filterbank and DCT x lifter are matrix products on v_mfma_f32_16x16x4_f32 (exact fp32): P[16 x 256] x
+//    FB^T[256 x 32] with the filterbank's zero blocks skipped (filters 0-15 end at bin 87, filters 16-25 begin
+//    at bin 77: 18 of 32 blocks of 16 bins), split over the four waves and summed in wave order; log;
+//    [16 x 32] x DCTL^T[32 x 32].  The B fragments are packed per lane on the host and stay in registers:
+//    blocks are persistent (four per CU) and walk the tiles with a grid stride.
+namespace fft512 {
+
+constexpr int kTile = 16;                   // frames per block pass
+constexpr int kEx = 576;                    // complex slots of a wave's exchange region (8 x 72)
+constexpr int kPS = 260;                    // floats per row of the power-spectrum tile (256 + 4: b128 reads spread over the banks)
+constexpr int kLS = 36;                     // floats per row of the log-mel tile
+constexpr int kMaxItems = 6;                // (filter tile, bin group) products per wave: 24 per block (the default filterbank has 18)
+constexpr int kLdsFloats = 4 * kEx * 2 + kTile * kPS + kTile * kLS + 2 * kTile + 2 * 56;
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+// natural-order DFT-8, forward sign (W_8 = exp(-2 pi i / 8))
+__device__ __forceinline__ void dft8(float (&r)[8], float (&i)[8]) {
+    constexpr float c = 0.70710678118654752f;
+    // x_j +- x_(j+4)
+    const float a0r = r[0] + r[4], a0i = i[0] + i[4], b0r = r[0] - r[4], b0i = i[0] - i[4];
+    const float a1r = r[1] + r[5], a1i = i[1] + i[5], t1r = r[1] - r[5], t1i = i[1] - i[5];
+    const float a2r = r[2] + r[6], a2i = i[2] + i[6], t2r = r[2] - r[6], t2i = i[2] - i[6];
+    const float a3r = r[3] + r[7], a3i = i[3] + i[7], t3r = r[3] - r[7], t3i = i[3] - i[7];
+    // odd branch: b_j = (x_j - x_(j+4)) W_8^j
+    const float b1r = c * (t1r + t1i), b1i = c * (t1i - t1r);
+    const float b2r = t2i, b2i = -t2r;
+    const float b3r = c * (t3i - t3r), b3i = -c * (t3r + t3i);
+    // DFT-4 of a -> X[0], X[2], X[4], X[6]
+    {
+        const float s0r = a0r + a2r, s0i = a0i + a2i, d0r = a0r - a2r, d0i = a0i - a2i;
+        const float s1r = a1r + a3r, s1i = a1i + a3i, d1r = a1r - a3r, d1i = a1i - a3i;
+        r[0] = s0r + s1r; i[0] = s0i + s1i;
+        r[4] = s0r - s1r; i[4] = s0i - s1i;
+        r[2] = d0r + d1i; i[2] = d0i - d1r;
+        r[6] = d0r - d1i; i[6] = d0i + d1r;
+    }
+    // DFT-4 of b -> X[1], X[3], X[5], X[7]
+    {
+        const float s0r = b0r + b2r, s0i = b0i + b2i, d0r = b0r - b2r, d0i = b0i - b2i;
+        const float s1r = b1r + b3r, s1i = b1i + b3i, d1r = b1r - b3r, d1i = b1i - b3i;
+        r[1] = s0r + s1r; i[1] = s0i + s1i;
+        r[5] = s0r - s1r; i[5] = s0i - s1i;
+        r[3] = d0r + d1i; i[3] = d0i - d1r;
+        r[7] = d0r - d1i; i[7] = d0i + d1r;
+    }
+}
+
+// w[(k - 1) * stride] = the twiddle of output k (registers: stride 1; the LDS table of step 2: stride 8)
+template <int STRIDE>
+__device__ __forceinline__ void twiddle(float (&r)[8], float (&i)[8], const float2* w) {
+#pragma unroll
+    for (int k = 1; k < 8; ++k) {
+        const float2 t = w[(k - 1) * STRIDE];
+        const float xr = r[k], xi = i[k];
+        r[k] = xr * t.x - xi * t.y;
+        i[k] = xr * t.y + xi * t.x;
+    }
+}
+
+// one frame's samples of this lane: n = lane + 64 a, pre-emphasised, zero past the frame / the signal.  The frame
+// index is uniform: a buffer descriptor at the frame's first sample (one before it when there is one, for the
+// pre-emphasis) whose range ends with the frame or the signal -- reads outside return zeros, so all sixteen
+// loads of a frame are issued back to back without a branch or a wait between them.  (A first version loaded
+// under `if (n < lim)`: every value was waited for where it was computed, 28 memory round trips per tile.)
+__device__ __forceinline__ void load_frame(const float* __restrict__ sig, int64_t n_samples, int n_frames,
+                                           int64_t total_frames, int64_t gframe, const MfccDev& d, int used, int lane,
+                                           float (&v)[8]) {
+    const bool live = gframe < total_frames;
+    const unsigned gf = live ? (unsigned)gframe : 0u;          // the launcher keeps total_frames below 2^31
+    const unsigned b = gf / (unsigned)n_frames;
+    const int64_t start = (int64_t)(gf - b * (unsigned)n_frames) * d.frame_step;
+    const int64_t left = n_samples - start;                    // samples from `start` to the end of the signal
+    const int lim = live ? (int)(left < used ? left : used) : 0;
+    const int back = start > 0 ? 1 : 0;                        // x[start - 1] exists
+    const unsigned long long base = reinterpret_cast<unsigned long long>(sig + (int64_t)b * n_samples + start - back);
+    const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)base);
+    const unsigned bhi = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32));
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<void*>(((unsigned long long)bhi << 32) | blo), (short)0,
+        __builtin_amdgcn_readfirstlane((lim + back) * 4), 0x00020000);
+    float cur[8], prev[8];
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+        const int o = (lane + 64 * a + back) * 4;
+        cur[a] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, o, 0, 0));
+        prev[a] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, o - 4, 0, 0));   // -4 at the signal's start: out of range, 0
+    }
+#pragma unroll
+    for (int a = 0; a < 8; ++a) v[a] = lane + 64 * a < lim ? cur[a] - d.preemph * prev[a] : 0.f;
+}
+
+__global__ __launch_bounds__(256, 4) void mfcc512_kernel(const float* __restrict__ sig, int64_t n_samples, int n_frames,
+                                                         int64_t total_frames, int n_tiles, MfccDev d,
+                                                         float* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) float smem[kLdsFloats];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float2* ex = reinterpret_cast<float2*>(smem) + wave * kEx;      // this wave's exchange region
+    float* P = smem + 4 * kEx * 2;                                  // [16][kPS] power spectra
+    float* LE = P + kTile * kPS;                                    // [16][kLS] log mel energies
+    float* en = LE + kTile * kLS;                                   // [2][16] frame energies (by tile parity)
+    const int hi = lane >> 3, lo = lane & 7, q = lane >> 4, row = lane & 15;
+
+    // twiddles: step 1's depend on the lane and stay in registers, step 2's (W_64^(c k), 56 values) sit in LDS
+    float2 w1[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) w1[k] = reinterpret_cast<const float2*>(d.f_tw1)[k * 64 + lane];
+    float2* w2 = reinterpret_cast<float2*>(en + 2 * kTile);
+    if (tid < 56) w2[tid] = reinterpret_cast<const float2*>(d.f_tw2)[tid];
+    __syncthreads();
+    // resident B fragments: products wave, wave + 4, ... of the list {tile 0 groups, tile 1 groups}
+    const int n_items = d.f_n0 + d.f_n1;
+    f32x4v fb[kMaxItems];
+    int a_off[kMaxItems];                                           // float offset of the A fragment in a P row
+#pragma unroll
+    for (int s = 0; s < kMaxItems; ++s) {
+        const int it = wave + 4 * s;
+        fb[s] = f32x4v{0.f, 0.f, 0.f, 0.f};
+        a_off[s] = 0;
+        if (it < n_items) {
+            const int t = it < d.f_n0 ? 0 : 1;
+            const int g = t ? d.f_lo1 + it - d.f_n0 : d.f_lo0 + it;
+            fb[s] = reinterpret_cast<const f32x4v*>(d.f_fb)[(t * 16 + g) * 64 + lane];
+            a_off[s] = 16 * g;
+        }
+    }
+    f32x4v db[2] = {f32x4v{0.f, 0.f, 0.f, 0.f}, f32x4v{0.f, 0.f, 0.f, 0.f}};
+    if (wave < 2) {
+        db[0] = reinterpret_cast<const f32x4v*>(d.f_dct)[(wave * 2 + 0) * 64 + lane];
+        db[1] = reinterpret_cast<const f32x4v*>(d.f_dct)[(wave * 2 + 1) * 64 + lane];
+    }
+    const int used = d.frame_len < 512 ? d.frame_len : 512;
+    const float scale = 0.25f / 512.f;                              // (1/2)^2 from the split, 1/nfft from powspec
+
+    int par = 0;
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, par ^= 1) {
+        // ---- FFT of this wave's two pairs of frames, power spectra into P
+#pragma unroll 1
+        for (int pp = 0; pp < 2; ++pp) {
+            const int r0 = 4 * wave + 2 * pp;                       // rows of the pair in the tile
+            const int64_t fa = (int64_t)tile * kTile + r0;
+            float xr[8], xi[8];
+            load_frame(sig, n_samples, n_frames, total_frames, fa, d, used, lane, xr);
+            load_frame(sig, n_samples, n_frames, total_frames, fa + 1, d, used, lane, xi);
+            // lane = 8b + c holds x[64a + 8b + c], a = 0..7
+            dft8(xr, xi);                                           // over a -> k0
+            twiddle<1>(xr, xi, w1);                                    // W_512^((8b + c) k0)
+#pragma unroll
+            for (int k0 = 0; k0 < 8; ++k0) ex[k0 * 72 + lane] = make_float2(xr[k0], xi[k0]);
+            wave_lds_sync();
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {                           // lane = 8 k0 + c
+                const float2 v = ex[hi * 72 + b * 8 + lo];
+                xr[b] = v.x; xi[b] = v.y;
+            }
+            dft8(xr, xi);                                           // over b -> k1
+            twiddle<8>(xr, xi, w2 + lo);                                    // W_64^(c k1)
+#pragma unroll
+            for (int k1 = 0; k1 < 8; ++k1) ex[hi * 72 + k1 * 9 + lo] = make_float2(xr[k1], xi[k1]);
+            wave_lds_sync();
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {                           // lane = 8 k0 + k1
+                const float2 v = ex[hi * 72 + lo * 9 + c];
+                xr[c] = v.x; xi[c] = v.y;
+            }
+            dft8(xr, xi);                                           // over c -> k2
+            // Z[k0 + 8 k1 + 64 k2] at slot k + (k >> 3)
+#pragma unroll
+            for (int k2 = 0; k2 < 8; ++k2) ex[k2 * 72 + lo * 9 + hi] = make_float2(xr[k2], xi[k2]);
+            wave_lds_sync();
+            // split the two spectra (A = (Z[k] + conj Z[N-k]) / 2, B = (Z[k] - conj Z[N-k]) / (2i)), power, energies
+            float ea = 0.f, eb = 0.f;
+#pragma unroll
+            for (int it = 0; it < 5; ++it) {
+                const int k = it < 4 ? lane + 64 * it : 256;
+                const int m = (512 - k) & 511;
+                const float2 p = ex[k + (k >> 3)], z = ex[m + (m >> 3)];
+                const float ar = p.x + z.x, ai = p.y - z.y, br = p.y + z.y, bi = z.x - p.x;
+                const float pa = (ar * ar + ai * ai) * scale, pb = (br * br + bi * bi) * scale;
+                if (it < 4) {
+                    P[r0 * kPS + k] = pa;
+                    P[(r0 + 1) * kPS + k] = pb;
+                    ea += pa;
+                    eb += pb;
+                } else if (lane == 0) {
+                    ea += pa;
+                    eb += pb;
+                }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                ea += __shfl_xor(ea, o);
+                eb += __shfl_xor(eb, o);
+            }
+            if (lane == 0) {
+                en[par * kTile + r0] = ea == 0.f ? kEps : ea;
+                en[par * kTile + r0 + 1] = eb == 0.f ? kEps : eb;
+            }
+        }
+        __syncthreads();                                            // P and en complete
+        // ---- mel filterbank: this wave's share of the (filter tile, bin group) products
+        f32x4v acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < kMaxItems; ++s) {
+            const int it = wave + 4 * s;
+            if (it < n_items) {                                     // uniform
+                const f32x4v a = *reinterpret_cast<const f32x4v*>(P + row * kPS + a_off[s] + 4 * q);
+                if (it < d.f_n0) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], fb[s][j], acc0, 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], fb[s][j], acc1, 0, 0, 0);
+                }
+            }
+        }
+        // partial sums into the wave's (now idle) exchange region
+        reinterpret_cast<f32x4v*>(ex)[lane] = acc0;
+        reinterpret_cast<f32x4v*>(ex)[64 + lane] = acc1;
+        __syncthreads();
+        if (tid < 128) {                                            // tile t = tid >> 6: sum in wave order, log
+            const f32x4v* p = reinterpret_cast<const f32x4v*>(smem) + tid;
+            f32x4v v = p[0];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) v += p[w * (kEx / 2)];
+            const int col = 16 * (tid >> 6) + row;                  // filter; rows = frames 4q + r
+#pragma unroll
+            for (int r = 0; r < 4; ++r) LE[(4 * q + r) * kLS + col] = logf(v[r] == 0.f ? kEps : v[r]);
+        }
+        __syncthreads();
+        // ---- DCT-II x lifter: waves 0 and 1, one tile of 16 cepstra each; the others go on to the next tile
+        if (wave < 2) {
+            f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const f32x4v a = *reinterpret_cast<const f32x4v*>(LE + row * kLS + 16 * g + 4 * q);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], db[g][j], acc, 0, 0, 0);
+            }
+            const int c = 16 * wave + row;
+            if (c < d.numcep) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int fr = 4 * q + r;
+                    const int64_t gf = (int64_t)tile * kTile + fr;
+                    float v = acc[r];
+                    if (c == 0 && d.append_energy) v = logf(en[par * kTile + fr]);
+                    if (gf < total_frames) out[gf * d.numcep + c] = v;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace fft512
+
 thread_local char g_merr[256] = "";
 int mfail(int code, const char* msg) {
     snprintf(g_merr, sizeof(g_merr), "%s", msg);
@@ -213,6 +489,8 @@ struct xvec_mfcc_plan {
     xvec_mfcc_cfg cfg;
     MfccDev dev;
     void* blob;   // one device allocation holding every table
+    bool fast;    // nfft == 512, nfilt <= 32, numcep <= 32: fft512::mfcc512_kernel
+    int num_cu;
 };
 
 extern "C" {
@@ -302,6 +580,58 @@ int xvec_mfcc_create(const xvec_mfcc_cfg* cfg, xvec_mfcc_plan** out) {
     p->dev.fboff_off = app_i(off);
     if (blob.size() & 1) blob.push_back(0.f);            // keep the per-wave regions 8-byte aligned
     p->dev.table_floats = (int)blob.size();
+    // tables of the nfft == 512 kernel, after the LDS image (16-byte aligned)
+    int f_tw1 = 0, f_tw2 = 0, f_fb = 0, f_dct = 0;
+    p->fast = (nfft == 512 && nfilt <= 32 && numcep <= 32);
+    if (p->fast) {
+        while (blob.size() & 3) blob.push_back(0.f);
+        f_tw1 = (int)blob.size();
+        for (int k = 1; k < 8; ++k)
+            for (int l = 0; l < 64; ++l) {
+                blob.push_back((float)std::cos(2.0 * M_PI * (l * k) / 512.0));
+                blob.push_back((float)(-std::sin(2.0 * M_PI * (l * k) / 512.0)));
+            }
+        f_tw2 = (int)blob.size();
+        for (int k = 1; k < 8; ++k)
+            for (int c = 0; c < 8; ++c) {
+                blob.push_back((float)std::cos(2.0 * M_PI * (c * k) / 64.0));
+                blob.push_back((float)(-std::sin(2.0 * M_PI * (c * k) / 64.0)));
+            }
+        // dense filterbank [32][256] (bin 256 never carries a weight: the last edge is exclusive) -> B fragments
+        // of v_mfma_f32_16x16x4_f32: lane l of product (tile t, group g) holds FB[16t + (l & 15)][16g + 4(l >> 4) + j]
+        std::vector<float> dense(32 * 256, 0.f);
+        for (int j = 0; j < nfilt; ++j)
+            for (int k = 0; k < off[j + 1] - off[j]; ++k)
+                if (lo[j] + k < 256) dense[j * 256 + lo[j] + k] = fbw[off[j] + k];
+        f_fb = (int)blob.size();
+        int g_lo[2] = {16, 16}, g_hi[2] = {0, 0};
+        for (int t = 0; t < 2; ++t)
+            for (int g = 0; g < 16; ++g)
+                for (int l = 0; l < 64; ++l)
+                    for (int j = 0; j < 4; ++j) {
+                        const float w = dense[(16 * t + (l & 15)) * 256 + 16 * g + 4 * (l >> 4) + j];
+                        blob.push_back(w);
+                        if (w != 0.f) {
+                            g_lo[t] = std::min(g_lo[t], g);
+                            g_hi[t] = std::max(g_hi[t], g + 1);
+                        }
+                    }
+        for (int t = 0; t < 2; ++t)
+            if (g_hi[t] <= g_lo[t]) g_lo[t] = g_hi[t] = 0;
+        p->dev.f_lo0 = g_lo[0];
+        p->dev.f_n0 = g_hi[0] - g_lo[0];
+        p->dev.f_lo1 = g_lo[1];
+        p->dev.f_n1 = g_hi[1] - g_lo[1];
+        if (p->dev.f_n0 + p->dev.f_n1 > 4 * fft512::kMaxItems) p->fast = false;   // an unusually dense filterbank
+        f_dct = (int)blob.size();
+        for (int t = 0; t < 2; ++t)
+            for (int g = 0; g < 2; ++g)
+                for (int l = 0; l < 64; ++l)
+                    for (int j = 0; j < 4; ++j) {
+                        const int c = 16 * t + (l & 15), m = 16 * g + 4 * (l >> 4) + j;
+                        blob.push_back(c < numcep && m < nfilt ? dctl[(size_t)c * dct_ld + m] : 0.f);
+                    }
+    }
     if (hipMalloc(&p->blob, blob.size() * 4) != hipSuccess) {
         delete p;
         return mfail(XVEC_ERR_HIP, "hipMalloc failed");
@@ -312,6 +642,10 @@ int xvec_mfcc_create(const xvec_mfcc_cfg* cfg, xvec_mfcc_plan** out) {
         return mfail(XVEC_ERR_HIP, "hipMemcpy failed");
     }
     p->dev.tables = static_cast<const float*>(p->blob);
+    p->dev.f_tw1 = p->dev.tables + f_tw1;
+    p->dev.f_tw2 = p->dev.tables + f_tw2;
+    p->dev.f_fb = p->dev.tables + f_fb;
+    p->dev.f_dct = p->dev.tables + f_dct;
     p->dev.frame_len = frame_len;
     p->dev.frame_step = frame_step;
     p->dev.nfft = nfft;
@@ -321,6 +655,10 @@ int xvec_mfcc_create(const xvec_mfcc_cfg* cfg, xvec_mfcc_plan** out) {
     p->dev.numcep = numcep;
     p->dev.append_energy = cfg->append_energy;
     p->dev.preemph = cfg->preemph;
+    {
+        hipDeviceProp_t prop;
+        p->num_cu = hipGetDeviceProperties(&prop, cfg->device) == hipSuccess ? prop.multiProcessorCount : 256;
+    }
     *out = p;
     return XVEC_OK;
 }
@@ -341,6 +679,15 @@ int xvec_mfcc(xvec_mfcc_plan* p, const float* signal, int32_t B, int64_t n_sampl
     if (!p || !signal || !out) return mfail(XVEC_ERR_ARG, "null argument");
     if (B < 1 || B > 65535 || n_samples < 1) return mfail(XVEC_ERR_ARG, "need 1 <= B <= 65535 and n_samples >= 1");
     const int n_frames = xvec_mfcc_frames(p, n_samples);
+    const int64_t total_frames = (int64_t)B * n_frames;
+    if (p->fast && total_frames < (int64_t(1) << 31) - fft512::kTile) {
+        const int n_tiles = (int)((total_frames + fft512::kTile - 1) / fft512::kTile);
+        const int grid = std::min(n_tiles, 4 * p->num_cu);
+        fft512::mfcc512_kernel<<<grid, 256, 0, static_cast<hipStream_t>(stream)>>>(signal, n_samples, n_frames, total_frames,
+                                                                              n_tiles, p->dev, out);
+        if (hipGetLastError() != hipSuccess) return mfail(XVEC_ERR_HIP, "mfcc kernel launch failed");
+        return XVEC_OK;
+    }
     const int per_wave = wave_floats(p->dev.nfft, p->dev.nbins);
     const size_t lds = ((size_t)per_wave * kWavesPerBlock + p->dev.table_floats) * 4;
     if (lds > 64 * 1024) {   // nfft 4096: opt in to the larger dynamic LDS once

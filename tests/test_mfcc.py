@@ -61,7 +61,7 @@ def test_c0_is_log_energy():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n_samples,B", [(48000, 3), (16000, 1), (401, 2), (250, 1), (47999, 2)])
+@pytest.mark.parametrize("n_samples,B", [(48000, 3), (16000, 1), (401, 2), (250, 1), (47999, 2), (48000, 64), (1000, 300)])
 def test_mfcc_kernel_vs_oracle(n_samples, B):
     import xvector_amd as xa
     from conftest import assert_parity
@@ -73,6 +73,24 @@ def test_mfcc_kernel_vs_oracle(n_samples, B):
     # fp32 kernel vs float64 oracle: per-frame norm-wise 1e-4 (the model casts features to fp32
     # anyway, reference main.py:137); element-wise 1e-3 of the mean magnitude (low-energy bands)
     assert_parity(got, ref, 1e-4, "mfcc", elem_tol=1e-3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", [dict(nfft=1024), dict(nfft=256, winlen=0.016), dict(nfft=2048, winlen=0.05, nfilt=40, numcep=13),
+                                dict(nfft=512, nfilt=40, numcep=20), dict(nfft=512, nfilt=20, numcep=13, lowfreq=300, highfreq=3400),
+                                dict(nfft=512, winlen=0.04), dict(nfft=512, appendEnergy=False, ceplifter=0, preemph=0.0)])
+def test_mfcc_other_configurations(kw):
+    """The package's other keyword arguments: nfft != 512 and nfilt > 32 take the general kernel, the rest the
+    nfft = 512 kernel with other tables (a frame longer than nfft is truncated, sigproc.powspec)."""
+    import xvector_amd as xa
+    from conftest import assert_parity
+    fe = xa.MfccFrontEnd(**kw)
+    waves = np.stack([_speechlike(20000, 70 + i) * (0.3 + 0.3 * i) for i in range(3)])
+    got = fe(torch.from_numpy(waves).to("cuda:0")).cpu().numpy()
+    okw = {k: v for k, v in kw.items()}
+    ref = np.stack([mo.mfcc(w, 16000, **{"numcep": 24, "nfilt": 26, "nfft": 512, **okw}) for w in waves])
+    assert got.shape == ref.shape
+    assert_parity(got, ref, 1e-4, f"mfcc {kw}", elem_tol=1e-3)
 
 
 @pytest.mark.gpu

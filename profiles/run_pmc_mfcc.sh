@@ -17,7 +17,7 @@ import csv, glob, collections
 agg = collections.defaultdict(list)
 for f in glob.glob("$out/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "mfcc_kernel" in r["Kernel_Name"]:
+        if "mfcc" in r["Kernel_Name"]:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k in sorted(agg):
     print(f"{k:28s} {sum(agg[k]) / len(agg[k]):16.1f}  n={len(agg[k])}")

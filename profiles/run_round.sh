@@ -17,6 +17,7 @@ python3 bench.py --steps 20 --warmup 5 --preroll 0 --cpu-budget 0 --no-secondary
 python3 bench.py --workload job --utterances 20000 --cpu-budget 0 > $out/bench_job20k.json 2> $out/bench_job20k.err; echo "bench job exit $?"
 python3 bench.py --workload job --utterances 20000 --dtype bf16 --cpu-budget 0 > $out/bench_job20k_bf16.json 2> $out/bench_job20k_bf16.err; echo "bench job bf16 exit $?"
 python3 bench.py --steps 20 --warmup 5 --workload wave --cpu-budget 0 > $out/bench_wave.json 2> $out/bench_wave.err; echo "bench wave exit $?"
+python3 bench.py --steps 20 --warmup 5 --workload wave --dtype bf16 --cpu-budget 0 > $out/bench_wave_bf16.json 2> $out/bench_wave_bf16.err; echo "bench wave bf16 exit $?"
 python3 bench.py --gpus 1 --force-collective --steps 20 --warmup 5 --cpu-budget 0 > $out/bench_collective1.json 2> $out/bench_collective1.err; echo "bench one-rank RCCL exit $?"
 fi
 for dt in fp32 bf16 bf16x3; do

@@ -230,84 +230,112 @@ constexpr int kTile = 16;                   // frames per block pass
 constexpr int kEx = 576;                    // complex slots of a wave's exchange region (8 x 72)
 constexpr int kPS = 260;                    // floats per row of the power-spectrum tile (256 + 4: b128 reads spread over the banks)
 constexpr int kLS = 36;                     // floats per row of the log-mel tile
-constexpr int kMaxItems = 6;                // (filter tile, bin group) products per wave: 24 per block (the default filterbank has 18)
+constexpr int kMaxItems = 5;                // (filter tile, bin group) products per wave: 20 per block (the default filterbank has 18)
 constexpr int kLdsFloats = 4 * kEx * 2 + kTile * kPS + kTile * kLS + 2 * kTile + 2 * 56;
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
-// natural-order DFT-8, forward sign (W_8 = exp(-2 pi i / 8))
-__device__ __forceinline__ void dft8(float (&r)[8], float (&i)[8]) {
+// A complex value is a register pair and the arithmetic below is PACKED fp32 (v_pk_add_f32 / v_pk_mul_f32 /
+// v_pk_fma_f32: both halves per instruction, the rate the 157 TFLOP/s vector peak is quoted on; nothing competes
+// for the issue slots here, unlike beside the MFMA streams of the TDNN kernels).  A complex add is one instruction;
+// the op_sel / neg modifiers of the packed forms fold the multiplications by -i and the conjugates of the
+// butterflies into the adds, and make a complex product two instructions with no swapped copy of the twiddle.
+typedef float c32 __attribute__((ext_vector_type(2)));
+// a + (-i) b = (a.x + b.y, a.y - b.x)
+__device__ __forceinline__ c32 cadd_mi(c32 a, c32 b) {
+    c32 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// a - (-i) b = (a.x - b.y, a.y + b.x)
+__device__ __forceinline__ c32 csub_mi(c32 a, c32 b) {
+    c32 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// a + conj(b), a - conj(b)
+__device__ __forceinline__ c32 cadd_conj(c32 a, c32 b) {
+    c32 r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ c32 csub_conj(c32 a, c32 b) {
+    c32 r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// x w = (x.x w.x - x.y w.y, x.x w.y + x.y w.x)
+__device__ __forceinline__ c32 cmul(c32 x, c32 w) {
+    c32 t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(x), "v"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(x), "v"(w), "v"(t));
+    return r;
+}
+
+// natural-order DFT-8, forward sign (W_8 = exp(-2 pi i / 8)): 28 packed instructions
+__device__ __forceinline__ void dft8(c32 (&x)[8]) {
     constexpr float c = 0.70710678118654752f;
     // x_j +- x_(j+4)
-    const float a0r = r[0] + r[4], a0i = i[0] + i[4], b0r = r[0] - r[4], b0i = i[0] - i[4];
-    const float a1r = r[1] + r[5], a1i = i[1] + i[5], t1r = r[1] - r[5], t1i = i[1] - i[5];
-    const float a2r = r[2] + r[6], a2i = i[2] + i[6], t2r = r[2] - r[6], t2i = i[2] - i[6];
-    const float a3r = r[3] + r[7], a3i = i[3] + i[7], t3r = r[3] - r[7], t3i = i[3] - i[7];
-    // odd branch: b_j = (x_j - x_(j+4)) W_8^j
-    const float b1r = c * (t1r + t1i), b1i = c * (t1i - t1r);
-    const float b2r = t2i, b2i = -t2r;
-    const float b3r = c * (t3i - t3r), b3i = -c * (t3r + t3i);
-    // DFT-4 of a -> X[0], X[2], X[4], X[6]
-    {
-        const float s0r = a0r + a2r, s0i = a0i + a2i, d0r = a0r - a2r, d0i = a0i - a2i;
-        const float s1r = a1r + a3r, s1i = a1i + a3i, d1r = a1r - a3r, d1i = a1i - a3i;
-        r[0] = s0r + s1r; i[0] = s0i + s1i;
-        r[4] = s0r - s1r; i[4] = s0i - s1i;
-        r[2] = d0r + d1i; i[2] = d0i - d1r;
-        r[6] = d0r - d1i; i[6] = d0i + d1r;
+    const c32 a0 = x[0] + x[4], b0 = x[0] - x[4];
+    const c32 a1 = x[1] + x[5], t1 = x[1] - x[5];
+    const c32 a2 = x[2] + x[6], t2 = x[2] - x[6];
+    const c32 a3 = x[3] + x[7], t3 = x[3] - x[7];
+    // odd branch: b_j = (x_j - x_(j+4)) W_8^j;  W_8 = (1 - i)/sqrt2, W_8^2 = -i (folded into the adds below),
+    // W_8^3 = -(1 + i)/sqrt2
+    const c32 b1 = cadd_mi(t1, t1) * c;
+    const c32 b3 = csub_mi(t3, t3) * (-c);
+    {   // DFT-4 of a -> X[0], X[2], X[4], X[6]
+        const c32 s0 = a0 + a2, d0 = a0 - a2, s1 = a1 + a3, d1 = a1 - a3;
+        x[0] = s0 + s1;
+        x[4] = s0 - s1;
+        x[2] = cadd_mi(d0, d1);
+        x[6] = csub_mi(d0, d1);
     }
-    // DFT-4 of b -> X[1], X[3], X[5], X[7]
-    {
-        const float s0r = b0r + b2r, s0i = b0i + b2i, d0r = b0r - b2r, d0i = b0i - b2i;
-        const float s1r = b1r + b3r, s1i = b1i + b3i, d1r = b1r - b3r, d1i = b1i - b3i;
-        r[1] = s0r + s1r; i[1] = s0i + s1i;
-        r[5] = s0r - s1r; i[5] = s0i - s1i;
-        r[3] = d0r + d1i; i[3] = d0i - d1r;
-        r[7] = d0r - d1i; i[7] = d0i + d1r;
+    {   // DFT-4 of b -> X[1], X[3], X[5], X[7]
+        const c32 s0 = cadd_mi(b0, t2), d0 = csub_mi(b0, t2), s1 = b1 + b3, d1 = b1 - b3;
+        x[1] = s0 + s1;
+        x[5] = s0 - s1;
+        x[3] = cadd_mi(d0, d1);
+        x[7] = csub_mi(d0, d1);
     }
 }
 
 // w[(k - 1) * stride] = the twiddle of output k (registers: stride 1; the LDS table of step 2: stride 8)
 template <int STRIDE>
-__device__ __forceinline__ void twiddle(float (&r)[8], float (&i)[8], const float2* w) {
+__device__ __forceinline__ void twiddle(c32 (&x)[8], const c32* w) {
 #pragma unroll
-    for (int k = 1; k < 8; ++k) {
-        const float2 t = w[(k - 1) * STRIDE];
-        const float xr = r[k], xi = i[k];
-        r[k] = xr * t.x - xi * t.y;
-        i[k] = xr * t.y + xi * t.x;
-    }
+    for (int k = 1; k < 8; ++k) x[k] = cmul(x[k], w[(k - 1) * STRIDE]);
 }
 
-// one frame's samples of this lane: n = lane + 64 a, pre-emphasised, zero past the frame / the signal.  The frame
-// index is uniform: a buffer descriptor at the frame's first sample (one before it when there is one, for the
-// pre-emphasis) whose range ends with the frame or the signal -- reads outside return zeros, so all sixteen
-// loads of a frame are issued back to back without a branch or a wait between them.  (A first version loaded
-// under `if (n < lim)`: every value was waited for where it was computed, 28 memory round trips per tile.)
-__device__ __forceinline__ void load_frame(const float* __restrict__ sig, int64_t n_samples, int n_frames,
-                                           int64_t total_frames, int64_t gframe, const MfccDev& d, int used, int lane,
-                                           float (&v)[8]) {
+// Descriptors of one frame's samples.  The frame index is uniform: the base is the frame's first sample (one before
+// it when there is one, for the pre-emphasis) and the range ends with the frame or the signal -- reads outside
+// return zeros, so the sixteen loads of a frame are issued back to back without a branch or a wait between them
+// (a first version loaded under `if (n < lim)`: every value was waited for where it was computed, 28 memory round
+// trips per tile).  `prev` ends one sample earlier than `cur`, so x[n-1] of the first sample past the frame reads 0 too.
+struct FrameSrc {
+    __amdgpu_buffer_rsrc_t cur, prev;
+    int back;
+};
+__device__ __forceinline__ FrameSrc frame_src(const float* __restrict__ sig, int64_t n_samples, int n_frames,
+                                              int64_t total_frames, int64_t gframe, const MfccDev& d, int used) {
     const bool live = gframe < total_frames;
     const unsigned gf = live ? (unsigned)gframe : 0u;          // the launcher keeps total_frames below 2^31
     const unsigned b = gf / (unsigned)n_frames;
     const int64_t start = (int64_t)(gf - b * (unsigned)n_frames) * d.frame_step;
     const int64_t left = n_samples - start;                    // samples from `start` to the end of the signal
     const int lim = live ? (int)(left < used ? left : used) : 0;
-    const int back = start > 0 ? 1 : 0;                        // x[start - 1] exists
-    const unsigned long long base = reinterpret_cast<unsigned long long>(sig + (int64_t)b * n_samples + start - back);
+    FrameSrc f;
+    f.back = start > 0 ? 1 : 0;                                // x[start - 1] exists
+    const unsigned long long base = reinterpret_cast<unsigned long long>(sig + (int64_t)b * n_samples + start - f.back);
     const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)base);
     const unsigned bhi = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32));
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-        reinterpret_cast<void*>(((unsigned long long)bhi << 32) | blo), (short)0,
-        __builtin_amdgcn_readfirstlane((lim + back) * 4), 0x00020000);
-    float cur[8], prev[8];
-#pragma unroll
-    for (int a = 0; a < 8; ++a) {
-        const int o = (lane + 64 * a + back) * 4;
-        cur[a] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, o, 0, 0));
-        prev[a] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, o - 4, 0, 0));   // -4 at the signal's start: out of range, 0
-    }
-#pragma unroll
-    for (int a = 0; a < 8; ++a) v[a] = lane + 64 * a < lim ? cur[a] - d.preemph * prev[a] : 0.f;
+    void* q = reinterpret_cast<void*>(((unsigned long long)bhi << 32) | blo);
+    const int n_cur = (lim + f.back) * 4, n_prev = n_cur >= 4 ? n_cur - 4 : 0;
+    f.cur = __builtin_amdgcn_make_buffer_rsrc(q, (short)0, __builtin_amdgcn_readfirstlane(n_cur), 0x00020000);
+    f.prev = __builtin_amdgcn_make_buffer_rsrc(q, (short)0, __builtin_amdgcn_readfirstlane(n_prev), 0x00020000);
+    return f;
+}
+__device__ __forceinline__ float ldf(__amdgpu_buffer_rsrc_t r, int off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
 }
 
 __global__ __launch_bounds__(256, 4) void mfcc512_kernel(const float* __restrict__ sig, int64_t n_samples, int n_frames,
@@ -316,18 +344,18 @@ __global__ __launch_bounds__(256, 4) void mfcc512_kernel(const float* __restrict
     __shared__ __attribute__((aligned(16))) float smem[kLdsFloats];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    float2* ex = reinterpret_cast<float2*>(smem) + wave * kEx;      // this wave's exchange region
+    c32* ex = reinterpret_cast<c32*>(smem) + wave * kEx;            // this wave's exchange region
     float* P = smem + 4 * kEx * 2;                                  // [16][kPS] power spectra
     float* LE = P + kTile * kPS;                                    // [16][kLS] log mel energies
     float* en = LE + kTile * kLS;                                   // [2][16] frame energies (by tile parity)
     const int hi = lane >> 3, lo = lane & 7, q = lane >> 4, row = lane & 15;
 
     // twiddles: step 1's depend on the lane and stay in registers, step 2's (W_64^(c k), 56 values) sit in LDS
-    float2 w1[7];
+    c32 w1[7];
 #pragma unroll
-    for (int k = 0; k < 7; ++k) w1[k] = reinterpret_cast<const float2*>(d.f_tw1)[k * 64 + lane];
-    float2* w2 = reinterpret_cast<float2*>(en + 2 * kTile);
-    if (tid < 56) w2[tid] = reinterpret_cast<const float2*>(d.f_tw2)[tid];
+    for (int k = 0; k < 7; ++k) w1[k] = reinterpret_cast<const c32*>(d.f_tw1)[k * 64 + lane];
+    c32* w2 = reinterpret_cast<c32*>(en + 2 * kTile);
+    if (tid < 56) w2[tid] = reinterpret_cast<const c32*>(d.f_tw2)[tid];
     __syncthreads();
     // resident B fragments: products wave, wave + 4, ... of the list {tile 0 groups, tile 1 groups}
     const int n_items = d.f_n0 + d.f_n1;
@@ -345,14 +373,23 @@ __global__ __launch_bounds__(256, 4) void mfcc512_kernel(const float* __restrict
             a_off[s] = 16 * g;
         }
     }
-    f32x4v db[2] = {f32x4v{0.f, 0.f, 0.f, 0.f}, f32x4v{0.f, 0.f, 0.f, 0.f}};
-    if (wave < 2) {
-        db[0] = reinterpret_cast<const f32x4v*>(d.f_dct)[(wave * 2 + 0) * 64 + lane];
-        db[1] = reinterpret_cast<const f32x4v*>(d.f_dct)[(wave * 2 + 1) * 64 + lane];
-    }
     const int used = d.frame_len < 512 ? d.frame_len : 512;
     const float scale = 0.25f / 512.f;                              // (1/2)^2 from the split, 1/nfft from powspec
 
+    // raw samples of a pair of frames (x[n] and x[n-1] of both).  Requesting them one pair ahead (during the split of
+    // the previous pair / the previous tile's matrix products) measured the same, interleaved on one box: with four
+    // waves per SIMD the memory latency is already covered, the kernel is issue-bound (VALU 50 %, LDS array 54 % busy).
+    c32 cur[8], prev[8];
+#define MF_REQUEST(fa_)                                                                                        \
+    {                                                                                                          \
+        const FrameSrc sa = frame_src(sig, n_samples, n_frames, total_frames, (fa_), d, used);                 \
+        const FrameSrc sb = frame_src(sig, n_samples, n_frames, total_frames, (fa_) + 1, d, used);             \
+        _Pragma("unroll") for (int a = 0; a < 8; ++a) {                                                        \
+            const int oa = (lane + 64 * a + sa.back) * 4, ob = (lane + 64 * a + sb.back) * 4;                  \
+            cur[a] = c32{ldf(sa.cur, oa), ldf(sb.cur, ob)};                                                    \
+            prev[a] = c32{ldf(sa.prev, oa - 4), ldf(sb.prev, ob - 4)}; /* -4 at a signal's start: out of range, 0 */ \
+        }                                                                                                      \
+    }
     int par = 0;
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, par ^= 1) {
         // ---- FFT of this wave's two pairs of frames, power spectra into P
@@ -360,44 +397,42 @@ __global__ __launch_bounds__(256, 4) void mfcc512_kernel(const float* __restrict
         for (int pp = 0; pp < 2; ++pp) {
             const int r0 = 4 * wave + 2 * pp;                       // rows of the pair in the tile
             const int64_t fa = (int64_t)tile * kTile + r0;
-            float xr[8], xi[8];
-            load_frame(sig, n_samples, n_frames, total_frames, fa, d, used, lane, xr);
-            load_frame(sig, n_samples, n_frames, total_frames, fa + 1, d, used, lane, xi);
+            // frame A is the real part, frame B the imaginary part: x[a] = sample 64a + lane, pre-emphasised
+            MF_REQUEST(fa)
+            c32 x[8];
+#pragma unroll
+            for (int a = 0; a < 8; ++a) x[a] = cur[a] - prev[a] * d.preemph;
             // lane = 8b + c holds x[64a + 8b + c], a = 0..7
-            dft8(xr, xi);                                           // over a -> k0
-            twiddle<1>(xr, xi, w1);                                    // W_512^((8b + c) k0)
+            dft8(x);                                                // over a -> k0
+            twiddle<1>(x, w1);                                      // W_512^((8b + c) k0)
 #pragma unroll
-            for (int k0 = 0; k0 < 8; ++k0) ex[k0 * 72 + lane] = make_float2(xr[k0], xi[k0]);
+            for (int k0 = 0; k0 < 8; ++k0) ex[k0 * 72 + lane] = x[k0];
             wave_lds_sync();
 #pragma unroll
-            for (int b = 0; b < 8; ++b) {                           // lane = 8 k0 + c
-                const float2 v = ex[hi * 72 + b * 8 + lo];
-                xr[b] = v.x; xi[b] = v.y;
-            }
-            dft8(xr, xi);                                           // over b -> k1
-            twiddle<8>(xr, xi, w2 + lo);                                    // W_64^(c k1)
+            for (int b = 0; b < 8; ++b) x[b] = ex[hi * 72 + b * 8 + lo];   // lane = 8 k0 + c
+            dft8(x);                                                // over b -> k1
+            twiddle<8>(x, w2 + lo);                                 // W_64^(c k1)
 #pragma unroll
-            for (int k1 = 0; k1 < 8; ++k1) ex[hi * 72 + k1 * 9 + lo] = make_float2(xr[k1], xi[k1]);
+            for (int k1 = 0; k1 < 8; ++k1) ex[hi * 72 + k1 * 9 + lo] = x[k1];
             wave_lds_sync();
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {                           // lane = 8 k0 + k1
-                const float2 v = ex[hi * 72 + lo * 9 + c];
-                xr[c] = v.x; xi[c] = v.y;
-            }
-            dft8(xr, xi);                                           // over c -> k2
+            for (int c = 0; c < 8; ++c) x[c] = ex[hi * 72 + lo * 9 + c];   // lane = 8 k0 + k1
+            dft8(x);                                                // over c -> k2
             // Z[k0 + 8 k1 + 64 k2] at slot k + (k >> 3)
 #pragma unroll
-            for (int k2 = 0; k2 < 8; ++k2) ex[k2 * 72 + lo * 9 + hi] = make_float2(xr[k2], xi[k2]);
+            for (int k2 = 0; k2 < 8; ++k2) ex[k2 * 72 + lo * 9 + hi] = x[k2];
             wave_lds_sync();
-            // split the two spectra (A = (Z[k] + conj Z[N-k]) / 2, B = (Z[k] - conj Z[N-k]) / (2i)), power, energies
+            // (frames past the end of the batch have empty descriptors: the loads return zeros)
+            // split the two spectra: A = (Z[k] + conj Z[N-k]) / 2, B = (Z[k] - conj Z[N-k]) / (2i); power, energies
             float ea = 0.f, eb = 0.f;
 #pragma unroll
             for (int it = 0; it < 5; ++it) {
                 const int k = it < 4 ? lane + 64 * it : 256;
                 const int m = (512 - k) & 511;
-                const float2 p = ex[k + (k >> 3)], z = ex[m + (m >> 3)];
-                const float ar = p.x + z.x, ai = p.y - z.y, br = p.y + z.y, bi = z.x - p.x;
-                const float pa = (ar * ar + ai * ai) * scale, pb = (br * br + bi * bi) * scale;
+                const c32 p = ex[k + (k >> 3)], z = ex[m + (m >> 3)];
+                const c32 sa2 = cadd_conj(p, z), sb2 = csub_conj(p, z);   // 2A, 2iB
+                const c32 qa = sa2 * sa2, qb = sb2 * sb2;
+                const float pa = (qa.x + qa.y) * scale, pb = (qb.x + qb.y) * scale;
                 if (it < 4) {
                     P[r0 * kPS + k] = pa;
                     P[(r0 + 1) * kPS + k] = pb;
@@ -451,6 +486,10 @@ __global__ __launch_bounds__(256, 4) void mfcc512_kernel(const float* __restrict
         __syncthreads();
         // ---- DCT-II x lifter: waves 0 and 1, one tile of 16 cepstra each; the others go on to the next tile
         if (wave < 2) {
+            // the DCT fragments (2 KiB per wave, L1/L2 hits) are fetched here rather than held through the FFTs
+            f32x4v db[2];
+            db[0] = reinterpret_cast<const f32x4v*>(d.f_dct)[(wave * 2 + 0) * 64 + lane];
+            db[1] = reinterpret_cast<const f32x4v*>(d.f_dct)[(wave * 2 + 1) * 64 + lane];
             f32x4v acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
@@ -472,6 +511,8 @@ __global__ __launch_bounds__(256, 4) void mfcc512_kernel(const float* __restrict
         }
     }
 }
+
+#undef MF_REQUEST
 
 }  // namespace fft512
 

@@ -119,6 +119,32 @@ __global__ void pack_tdnn_weight_ktile_kernel(const float* __restrict__ W, TdnnG
         Wt[i] = (__bf16)v;
     }
 }
+// The same for the bf16x3 form of tdnn_pp16.hip: every K-tile three times -- W_hi, W_lo = bf16(W - W_hi), W_hi again --
+// in the order its K loop meets them (hi slab x W_hi, hi slab x W_lo, lo slab x W_hi): [column block][3 * K-tile + j][256][64]
+__global__ void pack_tdnn_weight_ktile3_kernel(const float* __restrict__ W, TdnnGeom g, __bf16* __restrict__ Wt) {
+    const int64_t total = (int64_t)g.n_pad * g.k_pad * 3;
+    const int nk3 = 3 * (g.k_pad / 64);
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int w = (int)(i & 63), r = (int)((i >> 6) & 255);
+        const int64_t t = i >> 14;                       // (column block, K-tile of the tripled sequence)
+        const int cb = (int)(t / nk3), q3 = (int)(t % nk3);
+        const int q = q3 / 3, j = q3 % 3;
+        const int n = cb * 256 + (r & ~63) + 4 * (r & 15) + ((r >> 4) & 3);      // row order: pack_tdnn_weight_ktile_kernel
+        const int kd = tap_major_k(g, q * 64 + w);
+        const int tap = kd / g.tap_stride_src, c = kd % g.tap_stride_src;
+        float v = 0.f;
+        if (n < g.cout && tap < g.src_taps && c < g.src_cin)
+            v = W[(int64_t)n * (g.src_taps * g.src_cin) + tap * g.src_cin + c];
+        const __bf16 hi = (__bf16)v;
+        Wt[i] = j == 1 ? (__bf16)(v - (float)hi) : hi;
+    }
+}
+hipError_t launch_pack_tdnn_rows_bf16x3(const float* W, const TdnnGeom& geo, void* Wr48, hipStream_t s) {
+    if (geo.n_pad % 256 != 0) return hipSuccess;
+    pack_tdnn_weight_ktile3_kernel<<<1024, 256, 0, s>>>(W, geo, static_cast<__bf16*>(Wr48));
+    return hipGetLastError();
+}
 hipError_t launch_pack_tdnn_rows_bf16(const float* W, const TdnnGeom& geo, void* Wr16, hipStream_t s) {
     if (geo.n_pad % 256 != 0) return hipSuccess;        // tdnn_pp16.hip is not used for such a layer
     pack_tdnn_weight_ktile_kernel<<<1024, 256, 0, s>>>(W, geo, static_cast<__bf16*>(Wr16));
@@ -193,6 +219,31 @@ __global__ void unpack_rows_kernel(const TI* __restrict__ flat, int ld, int T_in
         const int c = (int)(i % C);
         dst[i] = (float)src[t * ld + c];
     }
+}
+
+// the same from the two bf16 planes of a bf16x3 activation buffer: y = hi + lo
+__global__ void unpack_rows_split_kernel(const __bf16* __restrict__ flat, int64_t plane_elems, int ld, int T_in, int T_out,
+                                         int C, float* __restrict__ y) {
+    const int u = blockIdx.y;
+    const int64_t total = (int64_t)T_out * C;
+    const __bf16* src = flat + (int64_t)u * T_in * ld;
+    float* dst = y + (int64_t)u * total;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t t = i / C;
+        const int c = (int)(i % C);
+        dst[i] = (float)src[t * ld + c] + (float)src[plane_elems + t * ld + c];
+    }
+}
+hipError_t launch_unpack_rows_split(const void* flat, int64_t plane_elems, int ld, int B, int T_in, int T_out, int C,
+                                    float* y, hipStream_t s) {
+    if (B <= 0 || T_out <= 0) return hipSuccess;
+    const int64_t per = (int64_t)T_out * C;
+    int gx = (int)((per + 255) / 256);
+    if (gx > 64) gx = 64;
+    unpack_rows_split_kernel<<<dim3((unsigned)gx, B), 256, 0, s>>>(static_cast<const __bf16*>(flat), plane_elems, ld, T_in,
+                                                                  T_out, C, y);
+    return hipGetLastError();
 }
 
 hipError_t launch_unpack_rows(const void* flat, bool in_bf16, int ld, int B, int T_in, int T_out, int C, float* y,

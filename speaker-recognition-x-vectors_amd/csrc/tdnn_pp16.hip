@@ -261,9 +261,21 @@ __device__ __forceinline__ void set_rows(const TdnnArgs& a, const Tile& t, int g
 // Scalar source offset of the activation K-tiles, stepped one K-tile at a time (taps innermost:
 // tap 0, 1, .., then the next 64-channel block): no division in the loop.
 struct KPos {
-    int tap, so;
+    int tap, so, ph;
 };
+// X3 (bf16x3: fp32 values carried as two bf16 planes hi + lo, x*W ~ x_hi*W_hi + x_hi*W_lo + x_lo*W_hi): every 64-channel
+// slab of a tap is THREE K-tiles -- the hi slab against W_hi, the hi slab again against W_lo, the lo slab (x_plane_bytes
+// further on: a scalar offset, the lanes' offsets do not change) against W_hi -- and the packed weights hold the
+// matching sequence W_hi | W_lo | W_hi per slab (pack.hip).  The K loop itself does not know: same tiles, same schedule,
+// three times as many K-tiles.
+template <bool X3>
 __device__ __forceinline__ void kstep(const TdnnArgs& a, KPos& k) {
+    if constexpr (X3) {
+        if (k.ph == 0) { k.ph = 1; return; }
+        if (k.ph == 1) { k.ph = 2; k.so += a.x_plane_bytes; return; }
+        k.ph = 0;
+        k.so -= a.x_plane_bytes;
+    }
     const int tapstep = a.tap_rows * a.ldx * 2;
     if (k.tap + 1 < a.n_taps) {
         k.tap += 1;
@@ -303,10 +315,10 @@ __device__ __forceinline__ void issue_head1(const TdnnArgs& a, const Stream& st,
     PP_ISSUE_A01(0, 0)
     PP_ISSUE_A23(mr, 0, 0)
 }
-template <bool POOL>
+template <bool POOL, bool X3>
 __device__ __forceinline__ void issue_head2(const TdnnArgs& a, const Stream& st, int mr) {
-    KPos k1 = {0, 0};
-    kstep(a, k1);
+    KPos k1 = {0, 0, 0};
+    kstep<X3>(a, k1);
     PP_ISSUE_A01(1, k1.so)
     PP_ISSUE_W(1, 1)
     PP_ISSUE_A23(mr, 1, k1.so)
@@ -351,8 +363,13 @@ constexpr int kBlk16 = 16 * kRowB;                // 16 rows of a 32-row block: 
 // k-step 0: in a tile's FIRST K-tile (kt_first, a constant of the enclosing PP_KTILE) the MFMA takes the bias of its
 // four-channel block as srcC and only WRITES the accumulator: the accumulators are never initialised (128 v_mov per
 // wave and tile, in the open at the head of every tile: 1 k cycles of each SIMD per tile, 3.5 % of a K = 512 tile)
+// (bf16x3 starts at ZERO and adds the bias in the epilogue, as the fp32 kernel does: on top of a large bias every MFMA's
+//  sum would be rounded at the bias's ulp, and the hi*lo / lo*hi terms -- 2^-9 of the product -- mostly lost: seen as 2e-4
+//  on the pooled standard deviations of a channel with |mean|/std = 4000, where the bar is 1e-4)
 #define PP_MF_S0(i_, f_, c_)                                                                                        \
-    if constexpr (kt_first)                                                                                         \
+    if constexpr (kt_first && X3)                                                                                   \
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(acc##i_##f_##c_) : "v"(__builtin_bit_cast(f32x4, af##i_##_##f_##0)), "v"(__builtin_bit_cast(f32x4, wf##c_##_0))); \
+    else if constexpr (kt_first)                                                                                    \
         asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %3" : "=&v"(acc##i_##f_##c_) : "v"(__builtin_bit_cast(f32x4, af##i_##_##f_##0)), "v"(__builtin_bit_cast(f32x4, wf##c_##_0)), "v"(bias4_##c_)); \
     else                                                                                                            \
         asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc##i_##f_##c_) : "v"(__builtin_bit_cast(f32x4, af##i_##_##f_##0)), "v"(__builtin_bit_cast(f32x4, wf##c_##_0)));
@@ -464,7 +481,7 @@ constexpr int kBlk16 = 16 * kRowB;                // 16 rows of a 32-row block: 
         PP_STAMP(9)                                                                 \
         PP_BARRIER()                                                                \
         PP_STAMP(10)                                                                \
-        kstep(a, k2);                                                               \
+        kstep<X3>(a, k2);                                                           \
         ++wq;                                                                       \
     }
 
@@ -567,16 +584,17 @@ struct SegCur {
 
 // One 32-frame group of this wave (acc row): v{f}{c} = accumulator of frame block f (frames 16 f + 4 q + e) and channel
 // col0 + c, bias inside.  limit = first row that does not belong to this block (its range end, or the end of the batch).
-template <bool RAGGED>
+// ADDB: the accumulators come WITHOUT the bias (bf16x3), bi = the bias of the lane's four channels.
+template <bool RAGGED, bool ADDB>
 __device__ __forceinline__ void pool_rows(const TdnnArgs& a, f32x4& v00, f32x4& v01, f32x4& v02, f32x4& v03, f32x4& v10,
                                           f32x4& v11, f32x4& v12, f32x4& v13, int64_t row_g, int64_t limit, int q, int col0,
-                                          int blk, int grp, bool cnt_writer, SegCur& sc, Seg& sg) {
+                                          int blk, int grp, bool cnt_writer, SegCur& sc, Seg& sg, const f32x4& bi) {
     const RowMap& m = a.out_map;
     if (row_g >= limit) return;
     // r = relu(z + bias), IN PLACE: as an expression in both paths below hipcc computes the 32 values up front into
     // 32 more registers, next to 128 live accumulators
-#define PQ_RELU(v_) _Pragma("unroll") for (int e = 0; e < 4; ++e) v_[e] = relu1(v_[e]);
-    PQ_RELU(v00) PQ_RELU(v01) PQ_RELU(v02) PQ_RELU(v03) PQ_RELU(v10) PQ_RELU(v11) PQ_RELU(v12) PQ_RELU(v13)
+#define PQ_RELU(v_, c_) _Pragma("unroll") for (int e = 0; e < 4; ++e) v_[e] = relu1(ADDB ? v_[e] + bi[c_] : v_[e]);
+    PQ_RELU(v00, 0) PQ_RELU(v01, 1) PQ_RELU(v02, 2) PQ_RELU(v03, 3) PQ_RELU(v10, 0) PQ_RELU(v11, 1) PQ_RELU(v12, 2) PQ_RELU(v13, 3)
 #undef PQ_RELU
     const int64_t g_end = row_g + 32 < limit ? row_g + 32 : limit;
     // utterances that ended before this group (the current one, and any that lay wholly in the other group's rows)
@@ -656,7 +674,7 @@ __device__ __forceinline__ void pool_finish(const TdnnArgs& a, int64_t limit, in
 }
 
 // One tile: K loop, request of the next tile's first K-tiles, epilogue.
-template <int MR, bool POOL>
+template <int MR, bool POOL, bool X3>
 __device__ __forceinline__ void process_tile(const TdnnArgs& a, char* smem, Stream& st, const Lane& ln,
                                              const Tile& t, const Tile& nxt, bool has_next, bool first, int n0, int nk,
                                              SegCur& sc, int64_t limit, int blk) {
@@ -719,9 +737,9 @@ __device__ __forceinline__ void process_tile(const TdnnArgs& a, char* smem, Stre
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dprev)::"memory");
     dsum[12] += dprev - dstart;            // head wait
 #endif
-    KPos k2 = {0, 0};                       // K-tile requested now (two ahead of the one computed), its W index,
-    kstep(a, k2);                           // the height of its tile, and whether there is anything to request
-    kstep(a, k2);
+    KPos k2 = {0, 0, 0};                    // K-tile requested now (two ahead of the one computed), its W index,
+    kstep<X3>(a, k2);                       // the height of its tile, and whether there is anything to request
+    kstep<X3>(a, k2);
     int wq = 2;
     int mr_req = MR;
     bool req = true;
@@ -734,6 +752,7 @@ __device__ __forceinline__ void process_tile(const TdnnArgs& a, char* smem, Stre
                 mr_req = nxt.mr;                                                                   \
                 k2.tap = 0;                                                                        \
                 k2.so = 0;                                                                         \
+                k2.ph = 0;                                                                         \
                 wq = 0;                                                                            \
             }                                                                                      \
         }
@@ -775,22 +794,33 @@ __device__ __forceinline__ void process_tile(const TdnnArgs& a, char* smem, Stre
         const int y_voff = (4 * (lane_e >> 4) * a.ldy + ln.wc * 64 + 4 * (lane_e & 15)) * 2;
         const float* cst_e = reinterpret_cast<const float*>(smem + kConstOff) + ln.wc * 64 + 4 * (lane_e & 15);
         const float4 sc = *reinterpret_cast<const float4*>(cst_e + 256), sh = *reinterpret_cast<const float4*>(cst_e + 512);
+        float4 bi_e = make_float4(0.f, 0.f, 0.f, 0.f);           // bf16x3: the bias is not in the accumulators (PP_MF_S0)
+        if constexpr (X3) bi_e = *reinterpret_cast<const float4*>(cst_e);
+#define PP_BZ(v_, b_) (X3 ? (v_) + (b_) : (v_))
 #define PP_STORE_F(i_, f_)                                                                             \
             _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                               \
-                const float v0 = fmaf(relu1(acc##i_##f_##0[e]), sc.x, sh.x);                         \
-                const float v1 = fmaf(relu1(acc##i_##f_##1[e]), sc.y, sh.y);                         \
-                const float v2 = fmaf(relu1(acc##i_##f_##2[e]), sc.z, sh.z);                         \
-                const float v3 = fmaf(relu1(acc##i_##f_##3[e]), sc.w, sh.w);                         \
+                const float v0 = fmaf(relu1(PP_BZ(acc##i_##f_##0[e], bi_e.x)), sc.x, sh.x);          \
+                const float v1 = fmaf(relu1(PP_BZ(acc##i_##f_##1[e], bi_e.y)), sc.y, sh.y);          \
+                const float v2 = fmaf(relu1(PP_BZ(acc##i_##f_##2[e], bi_e.z)), sc.z, sh.z);          \
+                const float v3 = fmaf(relu1(PP_BZ(acc##i_##f_##3[e], bi_e.w)), sc.w, sh.w);          \
                 const u32x2 pk = {__builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{v0, v1}, bf16x2)), \
                                   __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{v2, v3}, bf16x2))}; \
-                __builtin_amdgcn_raw_buffer_store_b64(pk, yrsrc, y_voff,                                  \
-                                                      (ln.grp * 32 * MR + 32 * i_ + 16 * f_ + e) * a.ldy * 2, 0); \
+                const int so_ = (ln.grp * 32 * MR + 32 * i_ + 16 * f_ + e) * a.ldy * 2;                   \
+                __builtin_amdgcn_raw_buffer_store_b64(pk, yrsrc, y_voff, so_, 0);                         \
+                if constexpr (X3) {   /* the remainders v - hi go to the lo plane, y_plane_bytes further on */ \
+                    const float l0 = v0 - __uint_as_float(pk[0] << 16), l1 = v1 - __uint_as_float(pk[0] & 0xffff0000u); \
+                    const float l2 = v2 - __uint_as_float(pk[1] << 16), l3 = v3 - __uint_as_float(pk[1] & 0xffff0000u); \
+                    const u32x2 pl = {__builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{l0, l1}, bf16x2)), \
+                                      __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{l2, l3}, bf16x2))}; \
+                    __builtin_amdgcn_raw_buffer_store_b64(pl, yrsrc, y_voff, so_ + a.y_plane_bytes, 0);  \
+                }                                                                                         \
             }
 #define PP_STORE(i_)                                                                                   \
         if (MR > i_ && row0 + 32 * i_ < t.valid_end) { PP_STORE_F(i_, 0) PP_STORE_F(i_, 1) }
         PP_STORE(0) PP_STORE(1) PP_STORE(2) PP_STORE(3)
 #undef PP_STORE
 #undef PP_STORE_F
+#undef PP_BZ
     } else {
         // (lane-derived values of this epilogue come from an opaque lane id: computed from ln.* the compiler hoists them
         //  out of the tile loop and carries them through the K loop, which has no register to spare)
@@ -811,11 +841,13 @@ __device__ __forceinline__ void process_tile(const TdnnArgs& a, char* smem, Stre
             sg.s1 = *reinterpret_cast<const f32x4*>(park + 16);
             sg.s2 = *reinterpret_cast<const f32x4*>(park + 32);
         }
+        f32x4 bi_p = {0.f, 0.f, 0.f, 0.f};                       // bf16x3: the bias of the lane's four channels (not in the accumulators)
+        if constexpr (X3) bi_p = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(smem + kConstOff) + ln.wc * 64 + 4 * r_e);
         PP_ESTAMP(0)
 #define PP_POOL(RG_, i_)                                                                               \
         if (MR > i_ && !(PP_KNOCK_ROWS && i_ > 0))                                                        \
-            pool_rows<RG_>(a, acc##i_##00, acc##i_##01, acc##i_##02, acc##i_##03, acc##i_##10, acc##i_##11, acc##i_##12, \
-                           acc##i_##13, row0 + 32 * i_, limit, q_e, col0, blk, ln.grp, cnt_writer, sc, sg);
+            pool_rows<RG_, X3>(a, acc##i_##00, acc##i_##01, acc##i_##02, acc##i_##03, acc##i_##10, acc##i_##11, acc##i_##12, \
+                               acc##i_##13, row0 + 32 * i_, limit, q_e, col0, blk, ln.grp, cnt_writer, sc, sg, bi_p);
         if (a.out_map.offsets == nullptr) {
             PP_POOL(false, 0) PP_ESTAMP(1) PP_POOL(false, 1) PP_ESTAMP(2) PP_POOL(false, 2) PP_ESTAMP(3) PP_POOL(false, 3) PP_ESTAMP(4)
             if (!has_next) pool_finish<false>(a, limit, q_e, col0, blk, ln.grp, cnt_writer, sc, sg);
@@ -849,7 +881,7 @@ __device__ __forceinline__ void process_tile(const TdnnArgs& a, char* smem, Stre
 #endif
 }
 
-template <bool POOL>
+template <bool POOL, bool X3>
 __global__ __launch_bounds__(kThreads, 2) void tdnn_pp_kernel(const TdnnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
@@ -858,7 +890,7 @@ __global__ __launch_bounds__(kThreads, 2) void tdnn_pp_kernel(const TdnnArgs a) 
     const int64_t u_begin = a.groups_total * (int64_t)prange / a.blocks_per_col;     // 64-frame units
     const int64_t u_end = a.groups_total * (int64_t)(prange + 1) / a.blocks_per_col;
     const int n0 = jcol * 256;
-    const int nk = a.n_taps * a.cpt;                    // K-tiles of 64 (even)
+    const int nk = a.n_taps * a.cpt * (X3 ? 3 : 1);     // K-tiles of 64 (even); bf16x3: three per slab (kstep)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -955,17 +987,17 @@ __global__ __launch_bounds__(kThreads, 2) void tdnn_pp_kernel(const TdnnArgs a) 
         set_rows(a, cur, ln.grp, ln.wc, st, st.cur);
         __syncthreads();                                   // constants visible; nobody reads LDS buffers yet
         issue_head1<POOL>(a, st, cur.mr);
-        issue_head2<POOL>(a, st, cur.mr);
+        issue_head2<POOL, X3>(a, st, cur.mr);
         for (int idx = 0; idx < nt; ++idx) {
             const bool has_next = idx + 1 < nt;
             Tile nxt = cur;
             if (has_next) nxt = tile_at(idx + 1, cur.m0 + 64 * cur.mr);
             if (cur.mr == 4)
-                process_tile<4, POOL>(a, smem, st, ln, cur, nxt, has_next, idx == 0, n0, nk, sc, limit, prange);
+                process_tile<4, POOL, X3>(a, smem, st, ln, cur, nxt, has_next, idx == 0, n0, nk, sc, limit, prange);
             else if (cur.mr == 3)
-                process_tile<3, POOL>(a, smem, st, ln, cur, nxt, has_next, idx == 0, n0, nk, sc, limit, prange);
+                process_tile<3, POOL, X3>(a, smem, st, ln, cur, nxt, has_next, idx == 0, n0, nk, sc, limit, prange);
             else
-                process_tile<2, POOL>(a, smem, st, ln, cur, nxt, has_next, idx == 0, n0, nk, sc, limit, prange);
+                process_tile<2, POOL, X3>(a, smem, st, ln, cur, nxt, has_next, idx == 0, n0, nk, sc, limit, prange);
             cur = nxt;
         }
 #ifdef XVEC_DIAG
@@ -999,17 +1031,21 @@ hipError_t launch_tdnn_pp16(const TdnnArgs& a, bool pool, hipStream_t s) {
         a.n_tiles <= 0)
         return hipErrorInvalidValue;
     const int grid = a.blocks_per_col * a.n_tiles;
-    if (pool) {
-        static LdsOptIn opt;
-        if (hipError_t e = opt.ensure(reinterpret_cast<const void*>(pp16::tdnn_pp_kernel<true>), pp16::kLdsBytes); e != hipSuccess)
-            return e;
-        pp16::tdnn_pp_kernel<true><<<dim3(grid), dim3(pp16::kThreads), pp16::kLdsBytes, s>>>(a);
-    } else {
-        static LdsOptIn opt;
-        if (hipError_t e = opt.ensure(reinterpret_cast<const void*>(pp16::tdnn_pp_kernel<false>), pp16::kLdsBytes); e != hipSuccess)
-            return e;
-        pp16::tdnn_pp_kernel<false><<<dim3(grid), dim3(pp16::kThreads), pp16::kLdsBytes, s>>>(a);
+#define PP_LAUNCH(POOL_, X3_)                                                                                       \
+    {                                                                                                               \
+        static LdsOptIn opt;                                                                                        \
+        if (hipError_t e = opt.ensure(reinterpret_cast<const void*>(pp16::tdnn_pp_kernel<POOL_, X3_>), pp16::kLdsBytes); \
+            e != hipSuccess)                                                                                        \
+            return e;                                                                                               \
+        pp16::tdnn_pp_kernel<POOL_, X3_><<<dim3(grid), dim3(pp16::kThreads), pp16::kLdsBytes, s>>>(a);              \
     }
+    const bool x3 = a.terms == 2;          // bf16x3: W = the three-K-tiles-per-slab packing, X / Y = hi and lo planes
+    if (pool) {
+        if (x3) PP_LAUNCH(true, true) else PP_LAUNCH(true, false)
+    } else {
+        if (x3) PP_LAUNCH(false, true) else PP_LAUNCH(false, false)
+    }
+#undef PP_LAUNCH
     return hipGetLastError();
 }
 

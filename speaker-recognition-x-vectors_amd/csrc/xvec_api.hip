@@ -71,6 +71,7 @@ struct xvec_handle {
     bool use_pp;                       // large-batch bf16 mapping enabled (XVEC_PP=0 disables it: A/B runs)
     int pp_min_tenths;                 // ... from this many tenths of a 64-frame unit per CU on (18; XVEC_PP_MIN_TENTHS: crossover sweeps)
     void* Wp48[XVEC_NUM_TDNN];         // bf16x3: per chunk W_hi then W_lo fragments (2x the size), fragment-major
+    void* Wr48[XVEC_NUM_TDNN];         // bf16x3, K-tile major for tdnn_pp16.hip: per K-tile W_hi | W_lo | W_hi (3x the size of Wr16)
     float* Wp[XVEC_NUM_TDNN];
     float* vec[XVEC_NUM_TDNN];         // bias | scale | shift, n_pad each
     bool tdnn_loaded[XVEC_NUM_TDNN];
@@ -244,14 +245,14 @@ int run_tdnn(xvec_handle* h, int layer, TdnnVariant v, const void* X, int ldx, i
     }
     StageTimer t(h, T_L1 + layer, s);
     // bf16, wide layers, enough rows to give every CU about two 64-frame units: the 256-channel
-    // ping-pong mapping (tdnn_pp16.hip); everything else (small batches, layer 1, narrow models, fp32,
-    // bf16x3) runs the 128x128 kernel
-    if (h->use_pp && !x3 && layer > 0 && (v == TdnnVariant::kBf16 || v == TdnnVariant::kBf16Pool) && g.n_pad % 256 == 0) {
+    // ping-pong mapping (tdnn_pp16.hip; bf16x3: the same kernel over three K-tiles per 64-channel slab); everything else
+    // (small batches, layer 1, narrow models, fp32) runs the 128x128 kernel
+    if (h->use_pp && layer > 0 && (v == TdnnVariant::kBf16 || v == TdnnVariant::kBf16Pool) && g.n_pad % 256 == 0) {
         const int n_cols = g.n_pad / 256;
         const int bpc = h->num_cu / n_cols;
         const int64_t units = (rows_out + 63) / 64;
         if (bpc >= 1 && units >= bpc && 10 * units >= h->pp_min_tenths * (int64_t)bpc) {   // >= 1.8 units per CU (measured crossover of layers 2-4, round 3: 51 utterances of 300 frames; layer 5: 18)
-            a.W = h->Wr16[layer];
+            a.W = x3 ? h->Wr48[layer] : h->Wr16[layer];
             a.n_tiles = n_cols;
             a.blocks_per_col = bpc;
             a.groups_total = units;
@@ -477,6 +478,7 @@ int xvec_create(const xvec_cfg* cfg, xvec_handle** out) {
         if (hipMalloc(&h->Wp16[i], (size_t)h->geo16[i].n_pad * h->geo16[i].k_pad * 2) != hipSuccess ||
             hipMalloc(&h->Wr16[i], (size_t)h->geo16[i].n_pad * h->geo16[i].k_pad * 2) != hipSuccess ||
             hipMalloc(&h->Wp48[i], (size_t)h->geo16[i].n_pad * h->geo16[i].k_pad * 2 * 2) != hipSuccess ||
+            hipMalloc(&h->Wr48[i], (size_t)h->geo16[i].n_pad * h->geo16[i].k_pad * 2 * 3) != hipSuccess ||
             hipMalloc(reinterpret_cast<void**>(&h->Wp[i]), (size_t)g.n_pad * g.k_pad * 4) != hipSuccess ||
             hipMalloc(reinterpret_cast<void**>(&h->vec[i]), (size_t)3 * g.n_pad * 4) != hipSuccess) {
             xvec_destroy(h);
@@ -516,6 +518,7 @@ void xvec_destroy(xvec_handle* h) {
         if (h->Wp16[i]) (void)hipFree(h->Wp16[i]);
         if (h->Wr16[i]) (void)hipFree(h->Wr16[i]);
         if (h->Wp48[i]) (void)hipFree(h->Wp48[i]);
+        if (h->Wr48[i]) (void)hipFree(h->Wr48[i]);
         if (h->vec[i]) (void)hipFree(h->vec[i]);
     }
     for (int i = 0; i < 3; ++i) {
@@ -550,6 +553,7 @@ int xvec_load_tdnn(xvec_handle* h, int layer, const float* weight, const float* 
                              static_cast<hipStream_t>(stream)));
     HIP_TRY(launch_pack_tdnn_bf16(weight, h->geo16[layer], h->Wp16[layer], static_cast<hipStream_t>(stream)));
     HIP_TRY(launch_pack_tdnn_rows_bf16(weight, h->geo16[layer], h->Wr16[layer], static_cast<hipStream_t>(stream)));
+    HIP_TRY(launch_pack_tdnn_rows_bf16x3(weight, h->geo16[layer], h->Wr48[layer], static_cast<hipStream_t>(stream)));
     {
         TdnnGeom g3 = h->geo16[layer];
         g3.terms = 2;
@@ -702,6 +706,22 @@ int xvec_tdnn_layer(xvec_handle* h, int layer, const float* x, int32_t B, int32_
     map.fixed_T = T;
     map.cum = g.ctx_span;
     const int To = T - g.ctx_span;
+    // bf16x3, layers 2-4 at the sizes xvec_forward gives to the large-batch kernel: that kernel, with its output as
+    // the two bf16 planes the next layer would read, joined (hi + lo) for the caller -- so that the per-layer entry runs
+    // what the whole path runs; otherwise the 128x128 kernel writes fp32 directly
+    if (x3 && layer > 0 && layer < XVEC_NUM_TDNN - 1 && h->use_pp && h->geo16[layer].n_pad % 256 == 0) {
+        const int bpc = h->num_cu / (h->geo16[layer].n_pad / 256);
+        const int64_t units = ((int64_t)B * To + 63) / 64;
+        if (bpc >= 1 && units >= bpc && 10 * units >= h->pp_min_tenths * (int64_t)bpc) {
+            const int64_t y_plane = p.rows_alloc * (int64_t)g.n_pad * 2;
+            void* y16 = ws + p.actB;
+            int rc = run_tdnn(h, layer, TdnnVariant::kBf16, xin, ldx, p.total, y16, (int64_t)B * To, map, nullptr, s, true,
+                              x_plane, y_plane);
+            if (rc) return rc;
+            HIP_TRY(launch_unpack_rows_split(y16, y_plane / 2, g.n_pad, B, To, To, g.cout, y, s));
+            return XVEC_OK;
+        }
+    }
     int rc = run_tdnn(h, layer, v, xin, ldx, p.total, yflat, (int64_t)B * To, map, nullptr, s, x3, x_plane, 0);
     if (rc) return rc;
     HIP_TRY(launch_unpack_rows(yflat, b16, g.n_pad, B, To, To, g.cout, y, s));

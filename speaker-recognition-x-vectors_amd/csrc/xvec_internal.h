@@ -127,6 +127,7 @@ hipError_t launch_tdnn(const TdnnArgs& a, TdnnVariant v, hipStream_t s);
 // Large-batch bf16 mapping (tdnn_pp16.hip, v_mfma_f32_16x16x32_bf16): 256-channel columns, 64-frame units.  Reads TdnnArgs with
 //   W = K-tile major bf16 [n_pad/256][k_pad/64][256][64] (K order as the fp32 packing, 64-element chunks), n_tiles = n_pad / 256,
 //   groups_total = ceil(rows / 64) units, blocks_per_col ranges per column (>= 1.8 units each: the measured crossover with the 128x128 kernel).
+//   terms == 2 (bf16x3): X / Y are hi and lo planes x_plane_bytes / y_plane_bytes apart, W the tripled packing below.
 hipError_t launch_tdnn_pp16(const TdnnArgs& a, bool pool, hipStream_t s);
 // Layer 1 of the bf16 path as a streaming kernel (tdnn_first.hip): weights resident in registers, 16-byte stores.
 // Reads TdnnArgs as the 128x128 kernel does (Wf = fragment-major bf16 weights); X holds the caller's fp32 rows.
@@ -134,6 +135,8 @@ bool tdnn_first_applicable(const TdnnArgs& a);
 hipError_t launch_tdnn_first(const TdnnArgs& a, int num_cu, hipStream_t s);
 // K-tile major bf16 copy of the packed weights for it
 hipError_t launch_pack_tdnn_rows_bf16(const float* W, const TdnnGeom& geo, void* Wr16, hipStream_t s);
+// ... and for its bf16x3 form (a.terms == 2): [n_pad/256][3 * k_pad/64][256][64], per K-tile W_hi | W_lo | W_hi
+hipError_t launch_pack_tdnn_rows_bf16x3(const float* W, const TdnnGeom& geo, void* Wr48, hipStream_t s);
 
 struct PoolArgs {
     const float* X;          // [B][T][C]
@@ -176,6 +179,8 @@ hipError_t launch_pack_rows(const float* x, const int64_t* offsets, int B, int T
 hipError_t launch_pack_rows_split(const float* x, int64_t rows, int C, int c_pad, int64_t plane_elems, void* out,
                                   hipStream_t s);
 // flat [rows, ld] (fp32 or bf16) -> compact fp32 y[B, T_out, C]
+hipError_t launch_unpack_rows_split(const void* flat, int64_t plane_elems, int ld, int B, int T_in, int T_out, int C,
+                                    float* y, hipStream_t s);
 hipError_t launch_unpack_rows(const void* flat, bool in_bf16, int ld, int B, int T_in, int T_out, int C,
                               float* y, hipStream_t s);
 

@@ -121,6 +121,68 @@ def test_bf16_fused_pooling_layer(gpu_model, sd42, synth, models, B, T):
     assert_parity(got, gpu_model.pooled_last_layer(h), 1e-2, "vs fp32 fused pooling")
 
 
+X3_SHAPES = [(52, 300), (63, 300), (128, 300), (256, 300), (70, 517)]
+
+
+@pytest.fixture(scope="module")
+def models_x3(sd42):
+    return _model(sd42, "bf16x3", pp=True), _model(sd42, "bf16x3", pp=False)
+
+
+@pytest.mark.parametrize("B,T", X3_SHAPES)
+def test_bf16x3_every_layer_every_element(gpu_model, sd42, synth, models_x3, B, T):
+    """bf16x3 (fp32 values as hi + lo bf16 planes, three bf16 products) on the large-batch kernel: the same tiles over
+    three K-tiles per 64-channel slab.  Every element of layers 2-4 (the planes joined by the per-layer entry) and the
+    fused pooling of layer 5 against the fp64 oracle at the fp32 bar, against the 128x128 kernel's bf16x3 and the
+    exact fp32 kernel, and repeat runs bit for bit."""
+    m_pp, m_old = models_x3
+    p64 = oracle.cast_params(float_params(sd42), torch.float64)
+    h = torch.as_tensor(synth.make_mfcc(B, T, seed=3000 + B)).to(DEV)
+    h = gpu_model.time_context_layers[0](h)
+    for i in range(1, 4):
+        got = m_pp.time_context_layers[i](h)
+        assert m_pp.last_dispatch()[i] == "pp", "the batch did not reach the large-batch kernel"
+        assert torch.equal(got, m_pp.time_context_layers[i](h)), f"layer {i}: repeat run differs"
+        ref = _oracle_layer(h.cpu(), p64, i)
+        assert_parity(got, ref, 1e-4, f"bf16x3 layer {i} B={B} T={T} vs oracle", elem_tol=1e-3)
+        old = m_old.time_context_layers[i](h)
+        assert m_old.last_dispatch()[i] == "tile128"
+        assert_parity(got, old, 2e-5, f"bf16x3 layer {i} B={B} T={T} large-batch vs 128x128 kernel", elem_tol=2e-4)
+        exact = gpu_model.time_context_layers[i](h)
+        assert_parity(got, exact, 2e-5, f"bf16x3 layer {i} B={B} T={T} vs the fp32 kernel", elem_tol=2e-4)
+        h = exact
+    got = m_pp.pooled_last_layer(h)
+    assert m_pp.last_dispatch()[4] == "pp"
+    assert torch.equal(got, m_pp.pooled_last_layer(h))
+    exact = gpu_model.pooled_last_layer(h)
+    assert_parity(got[:, :1500], exact[:, :1500], 1e-5, "bf16x3 pooled means vs the fp32 kernel")
+    assert_parity(got[:, 1500:], exact[:, 1500:], 1e-4, "bf16x3 pooled stds vs the fp32 kernel", elem_tol=1e-3)
+    idx = sorted({0, 1, B // 2, B - 1})
+    ref = torch.cat([oracle.stat_pool(_oracle_layer(h[j:j + 1].cpu(), p64, 4).double()) for j in idx])
+    assert_parity(got[idx][:, :1500], ref[:, :1500], 1e-4, "bf16x3 pooled means vs oracle")
+    assert_parity(got[idx][:, 1500:], ref[:, 1500:], 1e-4, "bf16x3 pooled stds vs oracle", elem_tol=1e-3)
+
+
+def test_bf16x3_whole_path_on_the_large_batch_kernels(gpu_model, sd42, synth, models_x3):
+    """x-vectors of a bench-size batch in bf16x3: layers 2-5 dispatched to the large-batch kernel, fp32 bar against the
+    exact fp32 path, sampled rows against the fp64 oracle; ragged batch too."""
+    m_pp, _ = models_x3
+    p64 = oracle.cast_params(float_params(sd42), torch.float64)
+    x = torch.as_tensor(synth.make_mfcc(256, 300, seed=31)).to(DEV)
+    got = m_pp.extract_x_vec(x)
+    assert m_pp.last_dispatch() == ["tile128", "pp", "pp", "pp", "pp"]
+    assert torch.equal(got, m_pp.extract_x_vec(x))
+    assert_parity(got, gpu_model.extract_x_vec(x), 1e-4, "bf16x3 x-vectors vs fp32")
+    idx = [0, 100, 255]
+    ref = oracle.extract_x_vec(x[idx].cpu().double(), p64, layer=6).float()
+    assert_parity(got[idx], ref, 1e-4, "bf16x3 x-vectors vs oracle")
+    lengths = torch.as_tensor(np.random.default_rng(5).integers(200, 1001, 96), dtype=torch.int32)
+    xr = torch.as_tensor(synth.make_mfcc(96, 1000, seed=32)).to(DEV)
+    got = m_pp.extract_x_vec(xr, lengths=lengths)
+    assert m_pp.last_dispatch()[1:] == ["pp"] * 4
+    assert_parity(got, gpu_model.extract_x_vec(xr, lengths=lengths), 1e-4, "bf16x3 ragged x-vectors vs fp32")
+
+
 @pytest.mark.parametrize("precision,tol", [("fp32", 1e-4), ("bf16x3", 1e-4)])
 def test_fused_pooling_layer_vs_oracle(sd42, synth, gpu_model, precision, tol):
     """The fp32 / bf16x3 pooling epilogue (tdnn_layer.hip) alone, every utterance against the fp64 oracle,
@@ -147,7 +209,7 @@ def _ill_conditioned_sd(sd42):
     return sd
 
 
-@pytest.mark.parametrize("precision,B,tol", [("fp32", 12, 1e-4), ("bf16x3", 12, 1e-4), ("bf16", 12, 1e-2), ("bf16", 96, 1e-2)])
+@pytest.mark.parametrize("precision,B,tol", [("fp32", 12, 1e-4), ("bf16x3", 12, 1e-4), ("bf16x3", 96, 1e-4), ("bf16", 12, 1e-2), ("bf16", 96, 1e-2)])
 def test_ill_conditioned_pooling_through_the_fused_path(sd42, synth, precision, B, tol):
     """|mean| >> std through layer 5's epilogue + pool_finalize (not the stand-alone stat_pool kernel): the pooled
     statistics AND the x-vectors against the fp64 oracle.  Round 2's raw fp32 sums (sum r, sum r^2) lose

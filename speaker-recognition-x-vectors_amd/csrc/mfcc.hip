@@ -322,7 +322,7 @@ __device__ __forceinline__ FrameSrc frame_src(const float* __restrict__ sig, int
     const unsigned b = gf / (unsigned)n_frames;
     const int64_t start = (int64_t)(gf - b * (unsigned)n_frames) * d.frame_step;
     const int64_t left = n_samples - start;                    // samples from `start` to the end of the signal
-    const int lim = live ? (int)(left < used ? left : used) : 0;
+    const int lim = live && left > 0 ? (int)(left < used ? left : used) : 0;   // (a frame step longer than the frame can start past the end)
     FrameSrc f;
     f.back = start > 0 ? 1 : 0;                                // x[start - 1] exists
     const unsigned long long base = reinterpret_cast<unsigned long long>(sig + (int64_t)b * n_samples + start - f.back);

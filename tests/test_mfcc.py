@@ -78,7 +78,8 @@ def test_mfcc_kernel_vs_oracle(n_samples, B):
 @pytest.mark.gpu
 @pytest.mark.parametrize("kw", [dict(nfft=1024), dict(nfft=256, winlen=0.016), dict(nfft=2048, winlen=0.05, nfilt=40, numcep=13),
                                 dict(nfft=512, nfilt=40, numcep=20), dict(nfft=512, nfilt=20, numcep=13, lowfreq=300, highfreq=3400),
-                                dict(nfft=512, winlen=0.04), dict(nfft=512, appendEnergy=False, ceplifter=0, preemph=0.0)])
+                                dict(nfft=512, winlen=0.04), dict(nfft=512, appendEnergy=False, ceplifter=0, preemph=0.0),
+                                dict(nfft=512, winlen=0.005, winstep=0.01), dict(nfft=1024, winlen=0.005, winstep=0.01)])
 def test_mfcc_other_configurations(kw):
     """The package's other keyword arguments: nfft != 512 and nfilt > 32 take the general kernel, the rest the
     nfft = 512 kernel with other tables (a frame longer than nfft is truncated, sigproc.powspec)."""

@@ -208,6 +208,177 @@ __global__ __launch_bounds__(256, 2) void tdnn_first_kernel(const TdnnArgs a) {
 
 }  // namespace first
 
+// ---- bf16x3 (fp32 values as hi + lo bf16 planes): the same streaming kernel with both halves of the weights
+// in registers.  W_hi and W_lo of 128 channels would be 256 VGPRs, so a block is EIGHT waves of 64 channels (2 x 8
+// fragments of each half: 128 VGPRs), one block per CU; the 512 threads fetch half a k-step (8 floats) of one frame each,
+// split it into bf16(x) and bf16(x - bf16(x)) and park the two halves in two LDS tiles; per k-step and accumulator three
+// MFMAs (x_hi W_hi, x_hi W_lo, x_lo W_hi); the epilogue stores bf16(v) and bf16(v - bf16(v)) to the two planes of the
+// activation buffer (y_plane_bytes apart).  Reads the caller's fp32 rows: the hi/lo split pass of the MFCCs
+// (pack_rows_split, 8 us per 256 x 300 frames) is not needed either.  128x128 form of this layer: 52 us; this: see DESIGN.
+namespace first3 {
+
+using first::Cur;
+using first::first_row_of;
+using first::kConstFloats;
+using first::kRowB;
+using first::kTileB;
+
+struct Staged {
+    u32x4 q0, q1;                          // 8 floats of the caller's fp32 rows
+};
+
+template <bool RAGGED>
+__device__ __forceinline__ void fetch(const TdnnArgs& a, int64_t g, Cur& cu, int rr, int sk, Staged& st) {
+    const RowMap& m = a.out_map;
+    const int64_t m0 = g * 32;
+    const int n_last = m.n_utts - 1;
+    while (cu.end <= m0 && cu.u < n_last) {
+        cu.u = __builtin_amdgcn_readfirstlane(cu.u + 1);
+        cu.end = first_row_of<RAGGED>(m, cu.u + 1);
+    }
+    int c = 0;                             // boundaries inside the group: frame rr lies c utterances past cu.u
+    {
+        int u = cu.u;
+        int64_t nxt = cu.end;
+        while (nxt < m0 + 32 && u < n_last) {
+            c += (m0 + rr >= nxt) ? 1 : 0;
+            u = __builtin_amdgcn_readfirstlane(u + 1);
+            nxt = first_row_of<RAGGED>(m, u + 1);
+        }
+    }
+    const int64_t row0 = m0 + (int64_t)cu.u * a.span;
+    const int64_t total = a.x_bytes ? a.x_bytes : a.x_rows * (int64_t)a.ldx * 4;
+    const __amdgpu_buffer_rsrc_t xr = make_rsrc_bounded(a.X, row0 * a.ldx * 4, total);
+    const int voff = ((rr + c * a.span) * a.ldx + 8 * sk) * 4;
+    st.q0 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, voff, 0, 0));
+    st.q1 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, voff, 16, 0));
+}
+
+// split into bf16 hi and lo, blank the K tail, park 16 bytes in each tile
+__device__ __forceinline__ void park(const TdnnArgs& a, char* tile_hi, int rr, int sk, const Staged& st) {
+    typedef float f32x2v __attribute__((ext_vector_type(2)));
+    float f[8];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        f[d] = __uint_as_float(st.q0[d]);
+        f[4 + d] = __uint_as_float(st.q1[d]);
+    }
+    const int k0 = 8 * sk;
+    if (k0 + 8 > a.kpt) {                  // values past kpt belong to the next frame and meet zero weights, but 0 x Inf is not 0
+#pragma unroll
+        for (int d = 0; d < 8; ++d)
+            if (k0 + d >= a.kpt) f[d] = 0.f;
+    }
+    u32x4 hi, lo;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        hi[d] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{f[2 * d], f[2 * d + 1]}, bf16x2));
+        const float l0 = f[2 * d] - __uint_as_float(hi[d] << 16), l1 = f[2 * d + 1] - __uint_as_float(hi[d] & 0xffff0000u);
+        lo[d] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{l0, l1}, bf16x2));
+    }
+    *reinterpret_cast<u32x4*>(tile_hi + rr * kRowB + sk * 16) = hi;
+    *reinterpret_cast<u32x4*>(tile_hi + kTileB + rr * kRowB + sk * 16) = lo;
+}
+
+template <bool RAGGED>
+__global__ __launch_bounds__(512) void tdnn_first3_kernel(const TdnnArgs a) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * kTileB + kConstFloats * 4];     // [buffer][hi | lo] tiles, constants
+    float* cst = reinterpret_cast<float*>(smem + 4 * kTileB);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    cst[tid] = a.bias[tid];
+    cst[512 + tid] = a.scale[tid];
+    cst[1024 + tid] = a.shift[tid];
+    // this wave's weights: channels [64*wave, +64); accumulator cg, lane r <-> channel 64*wave + 2r + cg.  The bf16x3
+    // fragment stream (pack.hip, terms == 2) holds per 32-channel tile and 64-wide chunk four W_hi k-step blocks, then four W_lo
+    u32x4 wh[2][8], wl[2][8];
+    {
+        const __amdgpu_buffer_rsrc_t wr = make_rsrc(a.Wf);
+#pragma unroll
+        for (int cg = 0; cg < 2; ++cg) {
+            const int ch = 64 * wave + 2 * r + cg;
+            const int voff = ((ch >> 5) * 16 * 64 + (ch & 31) + 32 * h) * 16;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const int blk = (ks >> 2) * 8 + (ks & 3);
+                wh[cg][ks] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wr, voff, blk * 1024, 0));
+                wl[cg][ks] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wr, voff, (blk + 4) * 1024, 0));
+            }
+        }
+    }
+    const int64_t g_begin = a.groups_total * (int64_t)blockIdx.x / gridDim.x;
+    const int64_t g_end = a.groups_total * (int64_t)(blockIdx.x + 1) / gridDim.x;
+    if (g_begin >= g_end) return;
+    Cur cu;
+    cu.u = __builtin_amdgcn_readfirstlane(utt_of_row(a.out_map, g_begin * 32));
+    cu.end = first_row_of<RAGGED>(a.out_map, cu.u + 1);
+    const int rr = tid >> 4, sk = tid & 15;        // staging: frame rr, half k-step sk
+    Staged sa, sb;                                 // two groups of look-ahead (see tdnn_first_kernel)
+    fetch<RAGGED>(a, g_begin, cu, rr, sk, sa);
+    park(a, smem, rr, sk, sa);
+    if (g_begin + 1 < g_end) fetch<RAGGED>(a, g_begin + 1, cu, rr, sk, sb);
+    __syncthreads();
+
+    const char* frag = smem + r * kRowB + 16 * h;
+    const float* c0 = cst + 64 * wave + 2 * r;
+    const float2 bi = *reinterpret_cast<const float2*>(c0), sc = *reinterpret_cast<const float2*>(c0 + 512),
+                 sh = *reinterpret_cast<const float2*>(c0 + 1024);
+    const int y_voff = (4 * h * a.ldy + 64 * wave + 2 * r) * 2;
+    typedef float f32x2v __attribute__((ext_vector_type(2)));
+#define XF_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#define XF3_MF(x_, w_, acc_) acc_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, x_), __builtin_bit_cast(bf16x8, w_), acc_, 0, 0, 0);
+#define XF3_GROUP(g_, buf_, ST_PARK, ST_FETCH)                                                                    \
+    {                                                                                                             \
+        if ((g_) + 2 < g_end) fetch<RAGGED>(a, (g_) + 2, cu, rr, sk, ST_FETCH);                                   \
+        f32x16 acc0, acc1;                                                                                        \
+        _Pragma("unroll") for (int e = 0; e < 16; ++e) acc0[e] = acc1[e] = 0.f;                                   \
+        const char* tile = frag + (buf_) * 2 * kTileB;                                                            \
+        _Pragma("unroll") for (int ks = 0; ks < 8; ++ks) {                                                        \
+            const u32x4 xh = *reinterpret_cast<const u32x4*>(tile + ks * 32);                                     \
+            const u32x4 xl = *reinterpret_cast<const u32x4*>(tile + kTileB + ks * 32);                            \
+            XF3_MF(xh, wh[0][ks], acc0) XF3_MF(xh, wh[1][ks], acc1)                                               \
+            XF3_MF(xh, wl[0][ks], acc0) XF3_MF(xh, wl[1][ks], acc1)                                               \
+            XF3_MF(xl, wh[0][ks], acc0) XF3_MF(xl, wh[1][ks], acc1)                                               \
+        }                                                                                                         \
+        if ((g_) + 1 < g_end) park(a, smem + ((buf_) ^ 1) * 2 * kTileB, rr, sk, ST_PARK);                         \
+        /* bias + ReLU + folded BatchNorm (tdnn_layer.py:30-39), then the two planes */                           \
+        const __amdgpu_buffer_rsrc_t yr = make_rsrc(static_cast<char*>(a.Y) + (g_) * 32 * (int64_t)a.ldy * 2);    \
+        _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                                          \
+            const float v0 = fmaf(fmaxf(acc0[e] + bi.x, 0.f), sc.x, sh.x);                                        \
+            const float v1 = fmaf(fmaxf(acc1[e] + bi.y, 0.f), sc.y, sh.y);                                        \
+            const unsigned ph = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{v0, v1}, bf16x2));    \
+            const float l0 = v0 - __uint_as_float(ph << 16), l1 = v1 - __uint_as_float(ph & 0xffff0000u);        \
+            const unsigned pl = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{l0, l1}, bf16x2));    \
+            const int so = ((e & 3) + 8 * (e >> 2)) * a.ldy * 2;                                                  \
+            __builtin_amdgcn_raw_buffer_store_b32(ph, yr, y_voff, so, 0);                                         \
+            __builtin_amdgcn_raw_buffer_store_b32(pl, yr, y_voff, so + a.y_plane_bytes, 0);                       \
+        }                                                                                                         \
+        XF_LDS_BARRIER()                                                                                          \
+    }
+    for (int64_t g = g_begin; g < g_end; g += 2) {
+        XF3_GROUP(g, 0, sb, sa)
+        if (g + 1 < g_end) XF3_GROUP(g + 1, 1, sa, sb)
+    }
+#undef XF3_GROUP
+#undef XF3_MF
+#undef XF_LDS_BARRIER
+}
+
+}  // namespace first3
+
+bool tdnn_first3_applicable(const TdnnArgs& a) {
+    return a.ldy == 512 && a.k_pad == 256 && a.n_taps == 1 && a.kpt <= 128 && a.terms == 2 && a.y_plane_bytes > 0 &&
+           (a.ldx * 4) % 16 == 0 && (reinterpret_cast<uintptr_t>(a.X) & 15) == 0 && a.groups_total > 0;
+}
+
+hipError_t launch_tdnn_first3(const TdnnArgs& a, int num_cu, hipStream_t s) {
+    const int grid = (int)(a.groups_total < num_cu ? a.groups_total : num_cu);
+    if (a.out_map.offsets != nullptr) first3::tdnn_first3_kernel<true><<<grid, 512, 0, s>>>(a);
+    else first3::tdnn_first3_kernel<false><<<grid, 512, 0, s>>>(a);
+    return hipGetLastError();
+}
+
 bool tdnn_first_applicable(const TdnnArgs& a) {
     return a.ldy == 512 && a.k_pad == 128 && a.n_taps == 1 && a.kpt <= 128 && a.terms == 1 && (a.ldx * 4) % 16 == 0 &&
            (reinterpret_cast<uintptr_t>(a.X) & 15) == 0 && a.groups_total > 0;

@@ -242,6 +242,7 @@ int run_tdnn(xvec_handle* h, int layer, TdnnVariant v, const void* X, int ldx, i
         a.x_plane_bytes = (int)x_plane;
         a.y_plane_bytes = (int)y_plane;
         a.x_bytes = x_rows > 0 ? x_plane + x_rows * (int64_t)ldx * 2 : 0;
+        if (v == TdnnVariant::kBf16FirstSrc32) a.x_bytes = 0;       // the caller's fp32 rows (tdnn_first3): x_rows * ldx * 4
     }
     StageTimer t(h, T_L1 + layer, s);
     // bf16, wide layers, enough rows to give every CU about two 64-frame units: the 256-channel
@@ -263,6 +264,13 @@ int run_tdnn(xvec_handle* h, int layer, TdnnVariant v, const void* X, int ldx, i
             h->last_kernel[layer] = XVEC_KERNEL_PP;
             return XVEC_OK;
         }
+    }
+    if (x3 && v == TdnnVariant::kBf16FirstSrc32) {      // bf16x3 layer 1 straight from the fp32 rows: only the streaming kernel does that
+        if (!(h->use_pp && layer == 0 && tdnn_first3_applicable(a)))
+            return fail(XVEC_ERR_STATE, "internal: bf16x3 layer 1 from fp32 rows needs the streaming kernel's shapes");
+        HIP_TRY(launch_tdnn_first3(a, h->num_cu, s));
+        h->last_kernel[layer] = XVEC_KERNEL_FIRST;
+        return XVEC_OK;
     }
     if (h->use_pp && layer == 0 && v == TdnnVariant::kBf16FirstSrc32 && tdnn_first_applicable(a)) {
         HIP_TRY(launch_tdnn_first(a, h->num_cu, s));
@@ -310,6 +318,14 @@ int finalize_pool(xvec_handle* h, const float* part, const int* part_cnt, const 
     return XVEC_OK;
 }
 
+// bf16x3 layer 1 can read the caller's fp32 rows itself (tdnn_first3: no hi/lo split pass) when the streaming kernel's
+// shapes hold (the reference's 24 MFCCs x 5 frames -> 512 channels do); run_tdnn checks the same through tdnn_first3_applicable
+bool first3_ok(const xvec_handle* h, const void* x_rows, int ldx) {
+    const TdnnGeom& g = h->geo16[0];
+    return h->use_pp && g.n_pad == 512 && g.k_pad == 128 && g.n_taps == 1 && g.kpt <= 128 && (ldx * 4) % 16 == 0 &&
+           (reinterpret_cast<uintptr_t>(x_rows) & 15) == 0;
+}
+
 // x_rows: [total, ldx] packed rows (offs_host == nullptr: B utterances of fixed_T rows each)
 int forward_rows(xvec_handle* h, const float* x_rows, int ldx, const int64_t* offs_dev, int B, int fixed_T,
                  const Plan& p, int mode, int dtype, float* out, char* ws, hipStream_t s) {
@@ -328,9 +344,10 @@ int forward_rows(xvec_handle* h, const float* x_rows, int ldx, const int64_t* of
     // bf16 mode the MFCC rows are first rounded to bf16 into the workspace (bf16x3: split into a hi
     // and a lo plane; every activation buffer then holds two bf16 planes in the space of one fp32).
     // Layer 5 carries the statistics-pooling epilogue: its [frames,1500] output stays on chip.
-    // (plain bf16: layer 1 reads the fp32 rows itself and rounds them in its staging path; bf16x3 needs the
-    // hi/lo split pass)
-    const TdnnVariant v1 = x3 ? TdnnVariant::kBf16First : b16 ? TdnnVariant::kBf16FirstSrc32 : TdnnVariant::kF32First;
+    // (plain bf16: layer 1 reads the fp32 rows itself and rounds them in its staging path; bf16x3 too when the
+    // streaming kernel's shapes hold -- first3_ok -- and otherwise needs the hi/lo split pass)
+    const bool first3 = x3 && first3_ok(h, x_rows, ldx);
+    const TdnnVariant v1 = x3 && !first3 ? TdnnVariant::kBf16First : b16 ? TdnnVariant::kBf16FirstSrc32 : TdnnVariant::kF32First;
     const TdnnVariant vm = b16 ? TdnnVariant::kBf16 : TdnnVariant::kF32;
     const TdnnVariant v5 = b16 ? TdnnVariant::kBf16Pool : TdnnVariant::kF32Pool;
     // every layer's output is compact: utterance u keeps len_u - cum frames after `cum` frames of
@@ -346,7 +363,7 @@ int forward_rows(xvec_handle* h, const float* x_rows, int ldx, const int64_t* of
     const int64_t act_plane = p.rows_alloc * (int64_t)nh * 2;        // bytes of one bf16 plane of an activation buffer
     int64_t in_plane = 0;
     if (b16 && p.total > 0x7fffffff) return fail(XVEC_ERR_ARG, "too many frames for one bf16 batch");
-    if (x3) {    // [total, ldx] fp32 -> bf16 hi and lo planes (same row stride in elements)
+    if (x3 && !first3) {    // [total, ldx] fp32 -> bf16 hi and lo planes (same row stride in elements)
         StageTimer t(h, T_PACK, s);
         void* x16 = ws + p.x16;
         in_plane = p.rows_alloc * (int64_t)ldx * 2;
@@ -689,11 +706,12 @@ int xvec_tdnn_layer(xvec_handle* h, int layer, const float* x, int32_t B, int32_
     const bool rows16 = in16 && !(b16 && layer == 0);
     void* xin = ws + (layer == 0 ? (rows16 ? p.x16 : p.xpad) : p.actA);
     int64_t x_plane = 0;
+    const bool l0_first3 = x3 && layer == 0 && first3_ok(h, ws + p.actB, ldx);   // layer 1 as xvec_forward runs it (tdnn_first3)
     if (x3) {   // fp32 rows first (padding to ldx), then the hi/lo split; bf16x3 returns fp32 directly
         void* x32 = ws + p.actB;
         HIP_TRY(launch_pack_rows(x, nullptr, B, T, g.src_cin, ldx, x32, false, s));
         x_plane = p.rows_alloc * (int64_t)ldx * 2;
-        HIP_TRY(launch_pack_rows_split(static_cast<const float*>(x32), p.total, ldx, ldx, x_plane / 2, xin, s));
+        if (!l0_first3) HIP_TRY(launch_pack_rows_split(static_cast<const float*>(x32), p.total, ldx, ldx, x_plane / 2, xin, s));
     } else {
         HIP_TRY(launch_pack_rows(x, nullptr, B, T, g.src_cin, ldx, xin, rows16, s));
     }
@@ -706,6 +724,15 @@ int xvec_tdnn_layer(xvec_handle* h, int layer, const float* x, int32_t B, int32_
     map.fixed_T = T;
     map.cum = g.ctx_span;
     const int To = T - g.ctx_span;
+    if (l0_first3) {    // fp32 rows in, the two bf16 planes out, joined for the caller
+        const int64_t y_plane = p.rows_alloc * (int64_t)g.n_pad * 2;
+        void* y16 = ws + p.actA;
+        int rc = run_tdnn(h, layer, TdnnVariant::kBf16FirstSrc32, ws + p.actB, ldx, p.total, y16, (int64_t)B * To, map, nullptr,
+                          s, true, 0, y_plane);
+        if (rc) return rc;
+        HIP_TRY(launch_unpack_rows_split(y16, y_plane / 2, g.n_pad, B, To, To, g.cout, y, s));
+        return XVEC_OK;
+    }
     // bf16x3, layers 2-4 at the sizes xvec_forward gives to the large-batch kernel: that kernel, with its output as
     // the two bf16 planes the next layer would read, joined (hi + lo) for the caller -- so that the per-layer entry runs
     // what the whole path runs; otherwise the 128x128 kernel writes fp32 directly

@@ -133,6 +133,9 @@ hipError_t launch_tdnn_pp16(const TdnnArgs& a, bool pool, hipStream_t s);
 // Reads TdnnArgs as the 128x128 kernel does (Wf = fragment-major bf16 weights); X holds the caller's fp32 rows.
 bool tdnn_first_applicable(const TdnnArgs& a);
 hipError_t launch_tdnn_first(const TdnnArgs& a, int num_cu, hipStream_t s);
+// ... and of the bf16x3 path: terms == 2, Wf = the bf16x3 fragment stream, Y = two bf16 planes y_plane_bytes apart; X the caller's fp32 rows
+bool tdnn_first3_applicable(const TdnnArgs& a);
+hipError_t launch_tdnn_first3(const TdnnArgs& a, int num_cu, hipStream_t s);
 // K-tile major bf16 copy of the packed weights for it
 hipError_t launch_pack_tdnn_rows_bf16(const float* W, const TdnnGeom& geo, void* Wr16, hipStream_t s);
 // ... and for its bf16x3 form (a.terms == 2): [n_pad/256][3 * k_pad/64][256][64], per K-tile W_hi | W_lo | W_hi

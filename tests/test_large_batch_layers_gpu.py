@@ -131,17 +131,17 @@ def models_x3(sd42):
 
 @pytest.mark.parametrize("B,T", X3_SHAPES)
 def test_bf16x3_every_layer_every_element(gpu_model, sd42, synth, models_x3, B, T):
-    """bf16x3 (fp32 values as hi + lo bf16 planes, three bf16 products) on the large-batch kernel: the same tiles over
-    three K-tiles per 64-channel slab.  Every element of layers 2-4 (the planes joined by the per-layer entry) and the
+    """bf16x3 (fp32 values as hi + lo bf16 planes, three bf16 products) on the large-batch kernels: layer 1 streaming
+    from the fp32 rows (tdnn_first3), layers 2-5 the bf16 tiles over three K-tiles per 64-channel slab.  Every element
+    of layers 1-4 (the planes joined by the per-layer entry) and the
     fused pooling of layer 5 against the fp64 oracle at the fp32 bar, against the 128x128 kernel's bf16x3 and the
     exact fp32 kernel, and repeat runs bit for bit."""
     m_pp, m_old = models_x3
     p64 = oracle.cast_params(float_params(sd42), torch.float64)
     h = torch.as_tensor(synth.make_mfcc(B, T, seed=3000 + B)).to(DEV)
-    h = gpu_model.time_context_layers[0](h)
-    for i in range(1, 4):
+    for i in range(0, 4):
         got = m_pp.time_context_layers[i](h)
-        assert m_pp.last_dispatch()[i] == "pp", "the batch did not reach the large-batch kernel"
+        assert m_pp.last_dispatch()[i] == ("first" if i == 0 else "pp"), "the batch did not reach the large-batch kernel"
         assert torch.equal(got, m_pp.time_context_layers[i](h)), f"layer {i}: repeat run differs"
         ref = _oracle_layer(h.cpu(), p64, i)
         assert_parity(got, ref, 1e-4, f"bf16x3 layer {i} B={B} T={T} vs oracle", elem_tol=1e-3)
@@ -170,7 +170,7 @@ def test_bf16x3_whole_path_on_the_large_batch_kernels(gpu_model, sd42, synth, mo
     p64 = oracle.cast_params(float_params(sd42), torch.float64)
     x = torch.as_tensor(synth.make_mfcc(256, 300, seed=31)).to(DEV)
     got = m_pp.extract_x_vec(x)
-    assert m_pp.last_dispatch() == ["tile128", "pp", "pp", "pp", "pp"]
+    assert m_pp.last_dispatch() == ["first", "pp", "pp", "pp", "pp"]
     assert torch.equal(got, m_pp.extract_x_vec(x))
     assert_parity(got, gpu_model.extract_x_vec(x), 1e-4, "bf16x3 x-vectors vs fp32")
     idx = [0, 100, 255]
@@ -179,7 +179,7 @@ def test_bf16x3_whole_path_on_the_large_batch_kernels(gpu_model, sd42, synth, mo
     lengths = torch.as_tensor(np.random.default_rng(5).integers(200, 1001, 96), dtype=torch.int32)
     xr = torch.as_tensor(synth.make_mfcc(96, 1000, seed=32)).to(DEV)
     got = m_pp.extract_x_vec(xr, lengths=lengths)
-    assert m_pp.last_dispatch()[1:] == ["pp"] * 4
+    assert m_pp.last_dispatch() == ["first", "pp", "pp", "pp", "pp"]
     assert_parity(got, gpu_model.extract_x_vec(xr, lengths=lengths), 1e-4, "bf16x3 ragged x-vectors vs fp32")
 
 

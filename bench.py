@@ -382,6 +382,21 @@ def main():
             "bf16_path_hbm_frac_algorithmic": round(K2 * B / d16 * BYTES_PER_UTT * T / 300.0 * 0.5 / HBM_PEAK, 4),
             "bf16_per_kernel_ms": {n: round(v, 4) for n, v in ms16.items()}})
         del m16
+        # bf16x3: fp32 values as two bf16 planes, three bf16 products -- the same 1e-4 bar as the headline
+        m3 = xa.XVectorModel(precision="bf16x3")
+        m3.load_state_dict(sd)
+        m3 = m3.to(dev).eval()
+        preroll(lambda: m3.extract_x_vec(x), min(args.preroll, 0.25))
+        for _ in range(5):
+            m3.extract_x_vec(x)
+        torch.cuda.synchronize(dev)
+        t3 = time.perf_counter()
+        for _ in range(K2):
+            m3.extract_x_vec(x)
+        torch.cuda.synchronize(dev)
+        d3 = time.perf_counter() - t3
+        secondary.update({"bf16x3_embeddings_per_s": round(K2 * B / d3, 1), "bf16x3_ms_per_step": round(d3 / K2 * 1e3, 4)})
+        del m3
         lens_np = xa.synth.make_lengths(B)
         Tr = int(lens_np.max())
         xr = torch.randn((B, Tr, 24), generator=gen, device=dev, dtype=torch.float32)
@@ -434,11 +449,13 @@ def main():
         # bf16x3 spends three bf16 MFMAs per algorithmic product: its roof is a third of the bf16 peak
         peak = {"fp32": FP32_MFMA_PEAK, "bf16": BF16_MFMA_PEAK, "bf16x3": BF16_MFMA_PEAK / 3}[args.dtype]
         # which kernel layers 2-4 actually went to, as the library reports it (xvec_get_dispatch): bf16 at this batch
-        # size runs the 256-channel ping-pong mapping (csrc/tdnn_pp16.hip); smaller batches, other CU counts, XVEC_PP=0
-        # and bf16x3 the 128x128 kernel (csrc/tdnn_layer.hip)
+        # and bf16x3 at this batch size run the 256-channel ping-pong mapping (csrc/tdnn_pp16.hip); smaller batches, other
+        # CU counts and XVEC_PP=0 the 128x128 kernel (csrc/tdnn_layer.hip)
         disp = model.last_dispatch(dev)
         pp16 = disp[1:4] == ["pp", "pp", "pp"]
-        dom_kernel = ("xvec::pp16::tdnn_pp_kernel<false> (layers 2-4, v_mfma_f32_16x16x32_bf16, LDS-DMA operands)" if pp16 else
+        dom_kernel = (f"xvec::pp16::tdnn_pp_kernel<false, {'true' if args.dtype == 'bf16x3' else 'false'}> (layers 2-4, "
+                      "v_mfma_f32_16x16x32_bf16, LDS-DMA operands"
+                      + (", three K-tiles per 64-channel slab)" if args.dtype == "bf16x3" else ")") if pp16 else
                       "xvec::tdnn_kernel<0,false,true,true,true,X3> (layers 2-4, bf16 MFMA"
                       + (", three products per k-step)" if args.dtype == "bf16x3" else ")") if bf else
                       "xvec::tdnn_kernel<0,false,true,false,false,false> (layers 2-4, fp32 MFMA)")
@@ -451,8 +468,8 @@ def main():
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
             tj = tj[args.dtype]                             # one section per arithmetic
             key = {"fp32": "tdnn_kernel<0, false, true, false, false, false>",
-                   "bf16": "pp16::tdnn_pp_kernel<false>" if pp16 else "tdnn_kernel<0, false, true, true, true, false>",
-                   "bf16x3": "tdnn_kernel<0, false, true, true, true, true>"}[args.dtype]
+                   "bf16": "pp16::tdnn_pp_kernel<false, false>" if pp16 else "tdnn_kernel<0, false, true, true, true, false>",
+                   "bf16x3": "pp16::tdnn_pp_kernel<false, true>" if pp16 else "tdnn_kernel<0, false, true, true, true, true>"}[args.dtype]
             traffic, traffic_src = tj[key]["hbm_bytes_per_launch"], tj["source"]
         except (OSError, KeyError, ValueError, StopIteration):
             pass

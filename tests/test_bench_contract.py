@@ -41,9 +41,9 @@ def test_bench_line(extra):
     assert c["value"] == c["legs"][c["leg"]]["embeddings_per_s"] and c["cores"] == c["legs"][c["leg"]]["threads"]
     cfg = d["config"]
     if not extra:      # the default line carries the other single-GPU configs as secondary fields (never `value`)
-        for key in ("bf16_embeddings_per_s", "bf16_roofline_frac", "ragged_utt_per_s", "ragged_valid_frames_per_s"):
+        for key in ("bf16_embeddings_per_s", "bf16_roofline_frac", "bf16x3_embeddings_per_s", "ragged_utt_per_s", "ragged_valid_frames_per_s"):
             assert isinstance(cfg[key], float) and cfg[key] > 0, key
-        assert cfg["bf16_embeddings_per_s"] > d["value"]          # bf16 matrix rate is 16x the fp32 one
+        assert cfg["bf16_embeddings_per_s"] > cfg["bf16x3_embeddings_per_s"] > d["value"]   # bf16 matrix rate is 16x the fp32 one
     else:
         assert "bf16_embeddings_per_s" not in cfg
 

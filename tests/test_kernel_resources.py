@@ -47,6 +47,6 @@ def test_no_kernel_uses_scratch():
             total += 1
             assert r.get("scratch", 0) == 0 and r.get("spill", 0) == 0, f"{src}: {name} uses scratch: {r}"
             assert r.get("vgprs", 0) <= 256, f"{src}: {name}: {r}"
-    assert len(results["tdnn_layer.hip"]) == 14 and len(results["tdnn_pp16.hip"]) == 4 and len(results["tdnn_first.hip"]) == 2
+    assert len(results["tdnn_layer.hip"]) == 14 and len(results["tdnn_pp16.hip"]) == 4 and len(results["tdnn_first.hip"]) == 4
     assert len(results["mfcc.hip"]) == 3
-    assert total >= 29
+    assert total >= 31

@@ -402,6 +402,18 @@ __global__ __launch_bounds__(256, 4) void mfcc512_kernel(const float* __restrict
             c32 x[8];
 #pragma unroll
             for (int a = 0; a < 8; ++a) x[a] = cur[a] - prev[a] * d.preemph;
+            // An all-zero frame (digital silence, or a frame that starts past the end of the signal) must come out as
+            // exact zeros -- the package substitutes eps for 0 before the log, -36.04 -- but packed with a live frame it
+            // picks up that frame's rounding noise through the split (1e-14 of its power: log ~ -30).  Its power
+            // scale is therefore 0 (uniform: one OR over the lane's samples and a ballot per frame).
+            unsigned ora = 0u, orb = 0u;
+#pragma unroll
+            for (int a = 0; a < 8; ++a) {
+                ora |= __float_as_uint(x[a].x);
+                orb |= __float_as_uint(x[a].y);
+            }
+            const float scale_a = __ballot((ora & 0x7fffffffu) != 0u) != 0ull ? scale : 0.f;
+            const float scale_b = __ballot((orb & 0x7fffffffu) != 0u) != 0ull ? scale : 0.f;
             // lane = 8b + c holds x[64a + 8b + c], a = 0..7
             dft8(x);                                                // over a -> k0
             twiddle<1>(x, w1);                                      // W_512^((8b + c) k0)
@@ -432,7 +444,7 @@ __global__ __launch_bounds__(256, 4) void mfcc512_kernel(const float* __restrict
                 const c32 p = ex[k + (k >> 3)], z = ex[m + (m >> 3)];
                 const c32 sa2 = cadd_conj(p, z), sb2 = csub_conj(p, z);   // 2A, 2iB
                 const c32 qa = sa2 * sa2, qb = sb2 * sb2;
-                const float pa = (qa.x + qa.y) * scale, pb = (qb.x + qb.y) * scale;
+                const float pa = (qa.x + qa.y) * scale_a, pb = (qb.x + qb.y) * scale_b;
                 if (it < 4) {
                     P[r0 * kPS + k] = pa;
                     P[(r0 + 1) * kPS + k] = pb;

@@ -95,6 +95,24 @@ def test_mfcc_other_configurations(kw):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("nfft", [512, 1024])
+def test_mfcc_digital_silence_inside_a_signal(nfft):
+    """Frames of exact zeros between live frames: the package puts eps where a power is 0 (log = -36.04).  The kernels
+    transform two frames as one complex signal; the silent one must not pick up the other's rounding noise."""
+    import xvector_amd as xa
+    from conftest import assert_parity
+    fe = xa.MfccFrontEnd(nfft=nfft)
+    waves = np.stack([_speechlike(16000, 90 + i) for i in range(2)])
+    waves[0, 5000:9000] = 0.0
+    waves[1, 12000:] = 0.0
+    got = fe(torch.from_numpy(waves).to("cuda:0")).cpu().numpy()
+    ref = np.stack([mo.mfcc(w, 16000, numcep=24, nfilt=26, nfft=nfft) for w in waves])
+    silent = np.isclose(ref[..., 0], np.log(np.finfo(float).eps))
+    assert silent.sum() > 20                      # the test does contain all-zero frames
+    assert_parity(got, ref, 1e-4, f"mfcc with digital silence, nfft={nfft}", elem_tol=1e-3)
+
+
+@pytest.mark.gpu
 def test_mfcc_feeds_the_extractor(gpu_model):
     """waveforms -> MFCC -> x-vectors entirely on the GPU, shapes as in the reference (299 x 24)."""
     import xvector_amd as xa

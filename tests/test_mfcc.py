@@ -75,6 +75,25 @@ def test_mfcc_kernel_vs_oracle(n_samples, B):
     assert_parity(got, ref, 1e-4, "mfcc", elem_tol=1e-3)
 
 
+def _mfcc_random_cases(n, seed):
+    rng = np.random.default_rng(seed)
+    return [(int(rng.integers(81, 30000)), int(rng.integers(1, 24))) for _ in range(n)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_samples,B", _mfcc_random_cases(12, 99))
+def test_mfcc_random_sizes(n_samples, B):
+    """Sizes nobody chose: frames are numbered through the batch in tiles of 16 and paired two to a transform, so
+    B x frames mod 32, the ragged last frame and the pair that straddles two utterances all vary."""
+    import xvector_amd as xa
+    from conftest import assert_parity
+    fe = xa.MfccFrontEnd()
+    waves = np.stack([_speechlike(n_samples, 500 + i) * (0.1 + 0.05 * i) for i in range(B)])
+    got = fe(torch.from_numpy(waves).to("cuda:0")).cpu().numpy()
+    ref = np.stack([mo.mfcc(w, 16000, numcep=24, nfilt=26, nfft=512) for w in waves])
+    assert_parity(got, ref, 1e-4, f"mfcc n={n_samples} B={B}", elem_tol=1e-3)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("kw", [dict(nfft=1024), dict(nfft=256, winlen=0.016), dict(nfft=2048, winlen=0.05, nfilt=40, numcep=13),
                                 dict(nfft=512, nfilt=40, numcep=20), dict(nfft=512, nfilt=20, numcep=13, lowfreq=300, highfreq=3400),

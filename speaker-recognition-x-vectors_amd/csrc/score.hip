@@ -3,6 +3,7 @@
 // C ABI: include/xvec_score.h.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 
@@ -29,7 +30,7 @@ struct GemmArgs {
     const double* colv;
     double* C;
     int64_t lda, ldb, ldc, M, N;
-    int K, tiles_n;
+    int K, tiles_n, n_tiles;
     double cst, scale;
 };
 
@@ -53,12 +54,15 @@ __device__ __forceinline__ f64x2 load2(const double* __restrict__ P, int64_t ld,
 // 4 waves as 2x2, each 64x64 = 4x4 MFMA tiles of 16x16 (C/D: col = lane&15, row = (lane>>4) + 4*reg).
 // K in 16-wide chunks through double-buffered LDS; the next chunk's global loads are in flight
 // while the 64 MFMAs (64 cycles each) of the current one run, so the kernel is matrix-pipe bound.
+// Persistent (round 3): two blocks per CU walk the tiles with a grid stride, and the first chunk of a block's NEXT tile is
+// requested before the epilogue of the current one, so a tile no longer starts with an exposed memory round trip.
 template <bool VEC>
 __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(const GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    const int lid = xcd_remap(blockIdx.x, gridDim.x);     // the column tiles of one row tile share an XCD's L2
-    const int64_t m0 = (int64_t)(lid / g.tiles_n) * kSM;
-    const int64_t n0 = (int64_t)(lid % g.tiles_n) * kSN;
+    int tile = xcd_remap(blockIdx.x, gridDim.x);          // the column tiles of one row tile share an XCD's L2
+    if (tile >= g.n_tiles) return;
+    int64_t m0 = (int64_t)(tile / g.tiles_n) * kSM;
+    int64_t n0 = (int64_t)(tile % g.tiles_n) * kSN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1, l15 = lane & 15, l4 = lane >> 4;
     const int piece = tid & 7, row0 = tid >> 3;
@@ -67,11 +71,6 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(const GemmArgs g) {
     double* sB = sm + 2 * kSM * kSLD;         // [2][kSN][kSLD]
 
     f64x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
-
     f64x2 ra[4], rb[4];
     auto gload = [&](int k0) {
 #pragma unroll
@@ -92,6 +91,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(const GemmArgs g) {
     gload(0);
     lstore(0);
     __syncthreads();
+  for (;;) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
     for (int c = 0; c < n_chunks; ++c) {
         const int buf = c & 1;
         if (c + 1 < n_chunks) gload((c + 1) * kSK);
@@ -115,17 +119,26 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(const GemmArgs g) {
         __syncthreads();
     }
 
+    // the block's next tile: its first chunk is requested now and flies under the epilogue
+    const int64_t em0 = m0, en0 = n0;
+    tile += gridDim.x;
+    const bool more = tile < g.n_tiles;
+    if (more) {
+        m0 = (int64_t)(tile / g.tiles_n) * kSM;
+        n0 = (int64_t)(tile % g.tiles_n) * kSN;
+        gload(0);
+    }
     // ---- epilogue: + rowv[m] + colv[n] + cst, * scale; 16 lanes write 128 contiguous bytes
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int64_t n = n0 + wc * 64 + j * 16 + l15;
+        const int64_t n = en0 + wc * 64 + j * 16 + l15;
         if (n >= g.N) continue;
         const double cv = (g.colv ? g.colv[n] : 0.0) + g.cst;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int64_t m = m0 + wr * 64 + i * 16 + l4 + 4 * r;
+                const int64_t m = em0 + wr * 64 + i * 16 + l4 + 4 * r;
                 if (m < g.M) {
                     const double rv = g.rowv ? g.rowv[m] : 0.0;
                     g.C[m * g.ldc + n] = g.scale * (acc[i][j][r] + rv + cv);
@@ -133,6 +146,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(const GemmArgs g) {
             }
         }
     }
+    if (!more) break;
+    lstore(0);              // (every wave has passed the barrier behind the last chunk: both buffers are free)
+    __syncthreads();
+  }
 }
 
 // out[i,d] = x[i,d] - mean[d]
@@ -194,7 +211,17 @@ int gemm_nt(const double* A, int64_t lda, const double* B, int64_t ldb, int64_t 
     if (M == 0 || N == 0) return XVEC_OK;
     const int64_t tm = (M + kSM - 1) / kSM, tn = (N + kSN - 1) / kSN;
     if (tm * tn > 0x7fffffff) return sfail(XVEC_ERR_ARG, "score matrix too large for one launch");
-    GemmArgs g{A, B, rowv, colv, C, lda, ldb, ldc, M, N, K, (int)tn, cst, scale};
+    GemmArgs g{A, B, rowv, colv, C, lda, ldb, ldc, M, N, K, (int)tn, (int)(tm * tn), cst, scale};
+    static int num_cu_cache[64] = {};          // per device: two persistent blocks per CU
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return sfail(XVEC_ERR_HIP, "hipGetDevice failed");
+    int num_cu = (dev >= 0 && dev < 64) ? num_cu_cache[dev] : 0;
+    if (num_cu == 0) {
+        hipDeviceProp_t prop;
+        num_cu = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
+        if (dev >= 0 && dev < 64) num_cu_cache[dev] = num_cu;
+    }
+    const unsigned grid = (unsigned)std::min<int64_t>(tm * tn, 2 * (int64_t)num_cu);
     const size_t lds = (size_t)2 * (kSM + kSN) * kSLD * sizeof(double);
     const bool vec = (K % 2 == 0) && (lda % 2 == 0) && (ldb % 2 == 0) && (reinterpret_cast<uintptr_t>(A) % 16 == 0) &&
                      (reinterpret_cast<uintptr_t>(B) % 16 == 0);
@@ -203,9 +230,9 @@ int gemm_nt(const double* A, int64_t lda, const double* B, int64_t ldb, int64_t 
                               : opt_s.ensure(reinterpret_cast<const void*>(&gemm_nt_f64_kernel<false>), (int)lds);
     if (ea != hipSuccess) return sfail(XVEC_ERR_HIP, "hipFuncSetAttribute failed: %s", hipGetErrorString(ea));
     if (vec)
-        gemm_nt_f64_kernel<true><<<(unsigned)(tm * tn), 256, lds, s>>>(g);
+        gemm_nt_f64_kernel<true><<<grid, 256, lds, s>>>(g);
     else
-        gemm_nt_f64_kernel<false><<<(unsigned)(tm * tn), 256, lds, s>>>(g);
+        gemm_nt_f64_kernel<false><<<grid, 256, lds, s>>>(g);
     return check_launch("gemm_nt_f64_kernel");
 }
 

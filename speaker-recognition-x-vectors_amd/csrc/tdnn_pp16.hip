@@ -13,6 +13,9 @@
 //     four accumulators of a frame hold four ADJACENT channels: the store epilogue writes 8 bytes per lane = whole
 //     128-byte row segments of four frames per instruction; the pooling epilogue reduces over the four lane quads
 //     with v_permlane16_swap + v_permlane32_swap and writes all three planes of a partial with one 16-byte store.
+// Template flag X3 (round 3): the bf16x3 arithmetic (fp32 values as hi + lo bf16 planes) on the same tiles -- the K
+// loop is untouched; kstep() walks three K-tiles per 64-channel slab (hi x W_hi, hi x W_lo, lo plane x W_hi), the store
+// epilogue writes both planes, and the accumulators start at zero with the bias added in the epilogue.
 // The rest of this header is tdnn_pp.hip's.
 //
 // The same implicit GEMM as tdnn_layer.hip (tdnn_layer.py:26-41 of the

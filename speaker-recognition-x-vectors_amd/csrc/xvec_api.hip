@@ -180,6 +180,16 @@ struct StageTimer {
     }
 };
 
+// The large-batch mapping (tdnn_pp16.hip) takes a layer when its column count is a multiple of 256 and every CU gets at least
+// pp_min_tenths / 10 units of 64 frames (1.8: the crossover with the 128x128 kernel measured in round 3 -- 51 utterances of
+// 300 frames for layers 2-4, 18 for layer 5; the same for bf16x3).  Returns the blocks per 256-channel column, 0 if not.
+int pp_blocks_per_col(const xvec_handle* h, int n_pad, int64_t rows_out) {
+    if (!h->use_pp || n_pad % 256 != 0) return 0;
+    const int bpc = h->num_cu / (n_pad / 256);
+    const int64_t units = (rows_out + 63) / 64;
+    return (bpc >= 1 && units >= bpc && 10 * units >= h->pp_min_tenths * (int64_t)bpc) ? bpc : 0;
+}
+
 // Launch one frame-level layer on flat rows.  The variant selects arithmetic and epilogue; bf16
 // variants use the bf16 packing (64-element chunks) of the layer's weights.
 // x3: bf16x3 arithmetic -- X (and Y, when it is bf16) are two bf16 planes `x_plane` / `y_plane` bytes apart
@@ -248,13 +258,11 @@ int run_tdnn(xvec_handle* h, int layer, TdnnVariant v, const void* X, int ldx, i
     // bf16, wide layers, enough rows to give every CU about two 64-frame units: the 256-channel
     // ping-pong mapping (tdnn_pp16.hip; bf16x3: the same kernel over three K-tiles per 64-channel slab); everything else
     // (small batches, layer 1, narrow models, fp32) runs the 128x128 kernel
-    if (h->use_pp && layer > 0 && (v == TdnnVariant::kBf16 || v == TdnnVariant::kBf16Pool) && g.n_pad % 256 == 0) {
-        const int n_cols = g.n_pad / 256;
-        const int bpc = h->num_cu / n_cols;
-        const int64_t units = (rows_out + 63) / 64;
-        if (bpc >= 1 && units >= bpc && 10 * units >= h->pp_min_tenths * (int64_t)bpc) {   // >= 1.8 units per CU (measured crossover of layers 2-4, round 3: 51 utterances of 300 frames; layer 5: 18)
+    if (layer > 0 && (v == TdnnVariant::kBf16 || v == TdnnVariant::kBf16Pool)) {
+        if (const int bpc = pp_blocks_per_col(h, g.n_pad, rows_out)) {
+            const int64_t units = (rows_out + 63) / 64;
             a.W = x3 ? h->Wr48[layer] : h->Wr16[layer];
-            a.n_tiles = n_cols;
+            a.n_tiles = g.n_pad / 256;
             a.blocks_per_col = bpc;
             a.groups_total = units;
             a.pair_period = 0;
@@ -736,10 +744,8 @@ int xvec_tdnn_layer(xvec_handle* h, int layer, const float* x, int32_t B, int32_
     // bf16x3, layers 2-4 at the sizes xvec_forward gives to the large-batch kernel: that kernel, with its output as
     // the two bf16 planes the next layer would read, joined (hi + lo) for the caller -- so that the per-layer entry runs
     // what the whole path runs; otherwise the 128x128 kernel writes fp32 directly
-    if (x3 && layer > 0 && layer < XVEC_NUM_TDNN - 1 && h->use_pp && h->geo16[layer].n_pad % 256 == 0) {
-        const int bpc = h->num_cu / (h->geo16[layer].n_pad / 256);
-        const int64_t units = ((int64_t)B * To + 63) / 64;
-        if (bpc >= 1 && units >= bpc && 10 * units >= h->pp_min_tenths * (int64_t)bpc) {
+    if (x3 && layer > 0 && layer < XVEC_NUM_TDNN - 1) {
+        if (pp_blocks_per_col(h, h->geo16[layer].n_pad, (int64_t)B * To)) {
             const int64_t y_plane = p.rows_alloc * (int64_t)g.n_pad * 2;
             void* y16 = ws + p.actB;
             int rc = run_tdnn(h, layer, TdnnVariant::kBf16, xin, ldx, p.total, y16, (int64_t)B * To, map, nullptr, s, true,

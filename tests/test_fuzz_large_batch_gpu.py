@@ -74,3 +74,32 @@ def test_random_shapes_large_batch_vs_128x128(engines, synth, gpu_model, precisi
         assert m_pp.last_dispatch()[2] == "pp"
         assert_parity(a, b, 1e-3 if precision == "bf16" else 2e-5, f"{precision} layer 3 B={B} T={T}",
                       elem_tol=1e-2 if precision == "bf16" else 2e-4)
+
+
+@pytest.mark.parametrize("B,T,ragged,seed", _cases(10, 77))
+def test_random_shapes_fp32_vs_oracle(gpu_model, sd42, synth, B, T, ragged, seed):
+    """The headline arithmetic at shapes nobody chose: pooled statistics and x-vectors of sampled utterances against the
+    fp64 oracle run per utterance on the un-padded slice (the reference's definition of a masked batch), at the path's bar."""
+    import xvector_oracle as oracle
+    from conftest import float_params
+    rng = np.random.default_rng(seed)
+    x = torch.as_tensor(synth.make_mfcc(B, T, seed=seed % 100000))
+    lengths = rng.integers(max(16, T // 4), T + 1, B).tolist() if ragged else None
+    if ragged:
+        lengths[int(rng.integers(B))] = T
+        lengths[int(rng.integers(B))] = 16
+    got_p = gpu_model.pooled(x.to(DEV), lengths=lengths).cpu()
+    got_x = gpu_model.extract_x_vec(x.to(DEV), lengths=lengths).cpu()
+    assert torch.equal(got_x, gpu_model.extract_x_vec(x.to(DEV), lengths=lengths).cpu()), "repeat run differs"
+    p64 = oracle.cast_params(float_params(sd42), torch.float64)
+    idx = sorted({0, B // 3, B // 2, B - 1} | ({int(np.argmin(lengths))} if ragged else set()))
+    for j in idx:
+        n = lengths[j] if ragged else T
+        xj = x[j:j + 1, :n].double()
+        ref_p = oracle.stat_pool(oracle.time_context_layers(xj, p64))
+        ref_x = oracle.extract_x_vec(xj, p64)
+        assert_parity(got_p[j:j + 1, :1500], ref_p[:, :1500], 1e-4, f"fp32 means utt {j} (n={n}) B={B} T={T} ragged={ragged}")
+        # (element-wise on the stds: with two pooled frames std = |a - b| / sqrt 2, and a channel with a ~ b carries the fp32
+        #  rounding of a and b at any relative size -- the fp32 reference against its own fp64 run too; norm-wise the bar holds)
+        assert_parity(got_p[j:j + 1, 1500:], ref_p[:, 1500:], 1e-4, f"fp32 stds utt {j} (n={n})", elem_tol=1e-3 if n >= 64 else 5e-2)
+        assert_parity(got_x[j:j + 1], ref_x, 1e-4, f"fp32 x-vector utt {j} (n={n})", elem_tol=1e-3)

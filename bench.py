@@ -20,6 +20,7 @@ The other BASELINE configs are parity-test cases, not the bench line; they can s
     --dtype bf16          configs[4]
 """
 import argparse
+import datetime
 import json
 import os
 import sys
@@ -27,6 +28,11 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+# dmabuf IPC: on this driver RCCL (and any sharing of device memory between processes) fails with
+# `hipIpcGetMemHandle: invalid argument` without it.  Set HERE -- before torch is imported, before any HIP call -- so that
+# BOTH launch forms have it: the ranks `torch.distributed.run ... bench.py` starts directly, and the ones self_launch() starts.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import numpy as np
 import torch
@@ -57,6 +63,14 @@ def usable_cpus():
     return n
 
 
+def traffic_key(dtype, pp16):
+    """Key of the dominant kernel (layers 2-4) in profiles/traffic.json: a substring of its demangled symbol, as rocprofv3
+    names it.  tests/test_host_logic.py checks every such key against the symbols of the built library."""
+    return {"fp32": "tdnn_kernel<0, false, true, false, false, false>",
+            "bf16": "pp16::tdnn_pp_kernel<false, false>" if pp16 else "tdnn_kernel<0, false, true, true, true, false>",
+            "bf16x3": "pp16::tdnn_pp_kernel<false, true>" if pp16 else "tdnn_kernel<0, false, true, true, true, true>"}[dtype]
+
+
 def total_flops(T):
     return sum(layer_flops(T)) + 2 * 3000 * 512
 
@@ -73,8 +87,7 @@ def self_launch(n, argv, port=0):
             port = sk.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL across processes needs it on this driver
+    env = dict(os.environ)                                # (HSA_ENABLE_IPC_MODE_LEGACY=0 is in it: module top)
     # stdout carries exactly the ranks' JSON line(s); anything else a rank or a backend prints there (gloo's
     # connection notes in a dry run) goes to stderr
     with subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1) as child:
@@ -96,7 +109,16 @@ def dry_run(args, world, rank):
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("gloo")
+        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=args.dist_timeout))
+    if args.fail_rank == rank:        # (tests) a rank that dies before the first barrier must end the job, not hang its peers
+        raise RuntimeError(f"bench.py --fail-rank {rank}: simulated rank failure before the first barrier")
+    if args.report_env:
+        # (tests) what every rank sees of the variable RCCL needs, gathered over the group and printed by rank 0 alone
+        vals = [os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")] * world
+        if collective:
+            dist.all_gather_object(vals, os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"))
+        if rank == 0:
+            print("ENV " + json.dumps({"HSA_ENABLE_IPC_MODE_LEGACY": vals}), file=sys.stderr, flush=True)
     fake = lambda x: torch.full((x.shape[0], 512), float(rank))      # noqa: E731
     if collective:
         dist.barrier()
@@ -167,6 +189,12 @@ def main():
                          "gloo backend, the extraction step replaced by a constant [B,512] tensor, no kernel figures; "
                          "the line says data: \"dry-run\" and its value means nothing")
     ap.add_argument("--master-port", type=int, default=0, help="rendezvous port of the self-launched ranks (0: pick a free one)")
+    ap.add_argument("--dist-timeout", type=float, default=180.0,
+                    help="seconds a rank waits in the rendezvous or in a collective for its peers before it gives up and exits "
+                         "non-zero (torch's default is 10 minutes: a rank that died before the first barrier would hold the "
+                         "others, and the driver, that long)")
+    ap.add_argument("--fail-rank", type=int, default=-1, help=argparse.SUPPRESS)      # tests: this rank raises before the first barrier
+    ap.add_argument("--report-env", action="store_true", help=argparse.SUPPRESS)     # tests (dry run): print the ranks' IPC variable
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -194,7 +222,9 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)
+        dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(seconds=args.dist_timeout))
+    if args.fail_rank == rank:
+        raise RuntimeError(f"bench.py --fail-rank {rank}: simulated rank failure before the first barrier")
 
     B, T, K, W = args.batch, args.frames, args.steps, args.warmup
     lengths = None
@@ -463,16 +493,14 @@ def main():
         # HBM bytes per launch of the dominant kernel come from the committed rocprofv3 --pmc pass of
         # this same command (profiles/traffic.json, written by profiles/summarize_pmc.py); counters
         # cannot be collected from inside the benchmark process.
-        traffic, traffic_src = None, None
+        traffic, traffic_src, traffic_err = None, None, None
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
             tj = tj[args.dtype]                             # one section per arithmetic
-            key = {"fp32": "tdnn_kernel<0, false, true, false, false, false>",
-                   "bf16": "pp16::tdnn_pp_kernel<false, false>" if pp16 else "tdnn_kernel<0, false, true, true, true, false>",
-                   "bf16x3": "pp16::tdnn_pp_kernel<false, true>" if pp16 else "tdnn_kernel<0, false, true, true, true, true>"}[args.dtype]
+            key = traffic_key(args.dtype, pp16)
             traffic, traffic_src = tj[key]["hbm_bytes_per_launch"], tj["source"]
-        except (OSError, KeyError, ValueError, StopIteration):
-            pass
+        except (OSError, KeyError, ValueError) as e:        # said out loud: a renamed or re-tiled kernel must not report stale bytes silently
+            traffic_err = f"profiles/traffic.json has no entry for this run's dominant kernel ({type(e).__name__}: {e}); re-run profiles/run_round.sh"
         out = {
             "metric": "x-vector embeddings/sec (300-frame utt)", "value": round(value, 1), "unit": "embeddings/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(dt / K * 1e3, 4),
@@ -500,6 +528,7 @@ def main():
                 "bound": "mfma", "kernel": dom_kernel,
                 "achieved": round(achieved, 2), "peak": peak / 1e12, "unit": "TFLOP/s",
                 "frac": round(achieved * 1e12 / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
+                **({"traffic_error": traffic_err} if traffic_err else {}),
                 "avg_launch_ms": round(dom_ms, 4), "flops_per_launch": dom_flops,
                 "per_kernel_ms": {n: round(v, 4) for n, v in avg_ms.items()},
                 "per_kernel_tflops": {n: round(lf[i] / (avg_ms[n] * 1e-3) / 1e12, 2) for i, n in enumerate(tdnn_names)},
@@ -533,4 +562,6 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    # a rank that fails exits non-zero (torch.distributed.run then ends its peers and fails the job; self_launch() passes
+    # that code on); never a re-exec -- this process may have touched the GPU
+    sys.exit(main() or 0)

@@ -20,7 +20,7 @@
  *     thread's current device as it found it (xvec_create included);
  *   - limits: at most 65535 utterances per call; input_size, hidden_size <= 8192; rows are addressed
  *     with 32-bit byte offsets, so (utterances x context + 264) x channels x element size must stay
- *     below 2^31 (XVEC_ERR_ARG otherwise -- split the batch);
+ *     below 2^31 (XVEC_ERR_TOO_LARGE otherwise -- split the batch);
  *   - every function returns XVEC_OK (0) or an error code and never throws; the message
  *     for the last error on the calling thread is available from xvec_last_error();
  *   - one handle per device; distinct handles may be used from distinct threads.
@@ -38,13 +38,23 @@ extern "C" {
 typedef struct xvec_handle xvec_handle;
 typedef void* xvec_stream; /* hipStream_t */
 
-enum { XVEC_OK = 0, XVEC_ERR_ARG = 1, XVEC_ERR_HIP = 2, XVEC_ERR_STATE = 3, XVEC_ERR_WORKSPACE = 4 };
+enum {
+    XVEC_OK = 0,
+    XVEC_ERR_ARG = 1,
+    XVEC_ERR_HIP = 2,
+    XVEC_ERR_STATE = 3,
+    XVEC_ERR_WORKSPACE = 4,
+    XVEC_ERR_TOO_LARGE = 5 /* the batch exceeds one of the per-call size limits below: the same data in several smaller calls works */
+};
 
 /* arithmetic of the frame-level stack (accumulation, pooling and the segment-level
  * affines are fp32 in both) */
 enum {
     XVEC_F32 = 0,   /* exact fp32 on v_mfma_f32_32x32x2_f32 (the reference's arithmetic) */
-    XVEC_BF16 = 1,  /* bf16 activations and weights (parity bar 1e-2) */
+    XVEC_BF16 = 1,  /* bf16 activations and weights (parity bar 1e-2).  Between layers this mode keeps the ReLU outputs (bf16) and
+                     * DEFERS each layer's eval BatchNorm (tdnn_layer.py:36-39) into the next layer's weights and bias -- an affine
+                     * map of a valid convolution's input folds exactly; layer 5's goes to the pooling merge.  The per-layer entry
+                     * points below still take and return the reference's tensors (BatchNorm applied). */
     /* fp32 values carried as two bf16 planes (hi + lo), three bf16 products per k-step
      * (x_hi*W_hi + x_lo*W_hi + x_hi*W_lo; every product is exact in the fp32 accumulator, what is
      * dropped is 2^-16 relative): fp32-level results (parity bar 1e-4, as XVEC_F32) at bf16 matrix rates */

@@ -66,7 +66,10 @@ hipError_t launch_pack_tdnn(const float* W, const float* bias, const float* g, c
 // Same matrix in bf16, fragment-major for v_mfma_f32_32x32x16_bf16: the 64 lanes' B operands of one
 // (32-channel column tile, 16-wide k-step) are one contiguous KiB, so a wave fetches them with a
 // single coalesced 16-byte-per-lane load and the weights never pass through LDS.
-__global__ void pack_tdnn_weight_frag_kernel(const float* __restrict__ W, TdnnGeom g, __bf16* __restrict__ Wf) {
+// in_scale (or nullptr): the folded BatchNorm scale of the PRODUCING layer, per input channel -- plain bf16 defers every
+// layer's BatchNorm into its consumer's weights (xvec_api.hip, refold): W'[n, tap, c] = W[n, tap, c] * scale_prev[c]
+__global__ void pack_tdnn_weight_frag_kernel(const float* __restrict__ W, const float* __restrict__ in_scale, TdnnGeom g,
+                                             __bf16* __restrict__ Wf) {
     // g.terms == 2 (bf16x3): the stream holds every 64-wide chunk twice -- its four W_hi k-step blocks,
     // then its four W_lo blocks, W = W_hi + W_lo + O(2^-17) -- as the kernel's XV_GLB3 reads them
     const int terms = g.terms > 1 ? g.terms : 1;
@@ -83,15 +86,17 @@ __global__ void pack_tdnn_weight_frag_kernel(const float* __restrict__ W, TdnnGe
         const int n = ct * 32 + (lane & 31), kd = tap_major_k(g, chunk * g.chunk_k + w);
         const int tap = kd / g.tap_stride_src, c = kd % g.tap_stride_src;
         float v = 0.f;
-        if (n < g.cout && tap < g.src_taps && c < g.src_cin)
+        if (n < g.cout && tap < g.src_taps && c < g.src_cin) {
             v = W[(int64_t)n * (g.src_taps * g.src_cin) + tap * g.src_cin + c];
+            if (in_scale) v *= in_scale[c];
+        }
         const __bf16 hi = (__bf16)v;
         Wf[i] = (terms > 1 && term == terms - 1) ? (__bf16)(v - (float)hi) : hi;
     }
 }
 
-hipError_t launch_pack_tdnn_bf16(const float* W, const TdnnGeom& geo, void* Wf16, hipStream_t s) {
-    pack_tdnn_weight_frag_kernel<<<1024, 256, 0, s>>>(W, geo, static_cast<__bf16*>(Wf16));
+hipError_t launch_pack_tdnn_bf16(const float* W, const float* in_scale, const TdnnGeom& geo, void* Wf16, hipStream_t s) {
+    pack_tdnn_weight_frag_kernel<<<1024, 256, 0, s>>>(W, in_scale, geo, static_cast<__bf16*>(Wf16));
     return hipGetLastError();
 }
 
@@ -100,7 +105,8 @@ hipError_t launch_pack_tdnn_bf16(const float* W, const TdnnGeom& geo, void* Wf16
 // DMA in 128-byte row slabs; a K-tile of a column block is then one contiguous 32 KiB, so the 256 CUs
 // that fetch the same tile at the same time spread over all L2 channels (128-byte slabs of plain rows,
 // 1-3 KiB apart, fall on two of them).
-__global__ void pack_tdnn_weight_ktile_kernel(const float* __restrict__ W, TdnnGeom g, __bf16* __restrict__ Wt) {
+__global__ void pack_tdnn_weight_ktile_kernel(const float* __restrict__ W, const float* __restrict__ in_scale, TdnnGeom g,
+                                              __bf16* __restrict__ Wt) {
     const int64_t total = (int64_t)g.n_pad * g.k_pad;
     const int nk = g.k_pad / 64;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
@@ -114,8 +120,10 @@ __global__ void pack_tdnn_weight_ktile_kernel(const float* __restrict__ W, TdnnG
         const int kd = tap_major_k(g, q * 64 + w);
         const int tap = kd / g.tap_stride_src, c = kd % g.tap_stride_src;
         float v = 0.f;
-        if (n < g.cout && tap < g.src_taps && c < g.src_cin)
+        if (n < g.cout && tap < g.src_taps && c < g.src_cin) {
             v = W[(int64_t)n * (g.src_taps * g.src_cin) + tap * g.src_cin + c];
+            if (in_scale) v *= in_scale[c];        // (see pack_tdnn_weight_frag_kernel)
+        }
         Wt[i] = (__bf16)v;
     }
 }
@@ -145,16 +153,47 @@ hipError_t launch_pack_tdnn_rows_bf16x3(const float* W, const TdnnGeom& geo, voi
     pack_tdnn_weight_ktile3_kernel<<<1024, 256, 0, s>>>(W, geo, static_cast<__bf16*>(Wr48));
     return hipGetLastError();
 }
-hipError_t launch_pack_tdnn_rows_bf16(const float* W, const TdnnGeom& geo, void* Wr16, hipStream_t s) {
+hipError_t launch_pack_tdnn_rows_bf16(const float* W, const float* in_scale, const TdnnGeom& geo, void* Wr16, hipStream_t s) {
     if (geo.n_pad % 256 != 0) return hipSuccess;        // tdnn_pp16.hip is not used for such a layer
-    pack_tdnn_weight_ktile_kernel<<<1024, 256, 0, s>>>(W, geo, static_cast<__bf16*>(Wr16));
+    pack_tdnn_weight_ktile_kernel<<<1024, 256, 0, s>>>(W, in_scale, geo, static_cast<__bf16*>(Wr16));
+    return hipGetLastError();
+}
+
+// Epilogue constants of a layer in plain bf16, whose BatchNorm is deferred into the NEXT layer (xvec_api.hip, refold):
+// this layer's bias absorbs the producing layer's folded shift,
+//   bias'[n] = bias[n] + sum_{tap, c} W[n, tap, c] * shift_prev[c]        (exact fp32 weights, fp64 sum)
+// and its own scale / shift leave the frame-level kernels (scale' = 1, shift' = 0: they store relu(z + bias')).
+// One wave per output channel; padded channels get bias' = scale' = shift' = 0 and stay exactly zero downstream.
+__global__ __launch_bounds__(64) void fold_bias_kernel(const float* __restrict__ W, const float* __restrict__ bias,
+                                                       const float* __restrict__ in_shift, int cout, int n_pad, int taps, int cin,
+                                                       float* __restrict__ out) {
+    const int n = blockIdx.x, lane = threadIdx.x;
+    double acc = 0.0;
+    if (n < cout && in_shift) {
+        const float* w = W + (int64_t)n * taps * cin;
+        for (int k = lane; k < taps * cin; k += 64) acc += (double)w[k] * (double)in_shift[k % cin];
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (lane == 0) {
+        out[n] = n < cout ? (float)((double)bias[n] + acc) : 0.f;
+        out[n_pad + n] = n < cout ? 1.f : 0.f;
+        out[2 * n_pad + n] = 0.f;
+    }
+}
+hipError_t launch_fold_bias(const float* W, const float* bias, const float* in_shift, const TdnnGeom& geo, float* vec16,
+                            hipStream_t s) {
+    fold_bias_kernel<<<geo.n_pad, 64, 0, s>>>(W, bias, in_shift, geo.cout, geo.n_pad, geo.src_taps, geo.src_cin, vec16);
     return hipGetLastError();
 }
 
 // x[B,T,C] -> packed rows out[offsets[u] + t][c_pad] for t < len_u (zero padded channels).
+// un_scale / un_shift (or nullptr): the folded BatchNorm of the layer that PRODUCED x, inverted on the way in --
+// r = (x - shift) / scale, 0 where scale == 0 (such a channel meets zero folded weights) -- for the per-layer entries in
+// plain bf16, whose kernels read the producing layer's relu output and carry its BatchNorm in their weights.
 template <typename TO>
 __global__ void pack_rows_kernel(const float* __restrict__ x, const int64_t* __restrict__ offsets, int T,
-                                 int C, int c_pad, TO* __restrict__ out) {
+                                 int C, int c_pad, TO* __restrict__ out, const float* __restrict__ un_scale,
+                                 const float* __restrict__ un_shift) {
     const int u = blockIdx.y;
     const int64_t off = offsets ? offsets[u] : (int64_t)u * T;
     const int64_t len = offsets ? offsets[u + 1] - off : T;
@@ -165,7 +204,12 @@ __global__ void pack_rows_kernel(const float* __restrict__ x, const int64_t* __r
          i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t t = i / c_pad;
         const int c = (int)(i % c_pad);
-        dst[i] = (TO)((c < C) ? src[t * C + c] : 0.f);
+        float v = (c < C) ? src[t * C + c] : 0.f;
+        if (un_scale && c < C) {
+            const float sc = un_scale[c];
+            v = sc != 0.f ? (v - un_shift[c]) / sc : 0.f;
+        }
+        dst[i] = (TO)v;
     }
 }
 
@@ -192,23 +236,24 @@ hipError_t launch_pack_rows_split(const float* x, int64_t rows, int C, int c_pad
 }
 
 hipError_t launch_pack_rows(const float* x, const int64_t* offsets, int B, int T, int C, int c_pad,
-                            void* out, bool out_bf16, hipStream_t s) {
+                            void* out, bool out_bf16, hipStream_t s, const float* un_scale, const float* un_shift) {
     if (B <= 0) return hipSuccess;
     const int64_t per = (int64_t)T * c_pad;
     int64_t gx = (per + 255) / 256;
     const int64_t cap = B >= 32 ? 64 : 2048 / B;   // enough blocks to fill the chip for small B
     if (gx > cap) gx = cap;
     if (out_bf16)
-        pack_rows_kernel<__bf16><<<dim3((unsigned)gx, B), 256, 0, s>>>(x, offsets, T, C, c_pad, static_cast<__bf16*>(out));
+        pack_rows_kernel<__bf16><<<dim3((unsigned)gx, B), 256, 0, s>>>(x, offsets, T, C, c_pad, static_cast<__bf16*>(out), un_scale, un_shift);
     else
-        pack_rows_kernel<float><<<dim3((unsigned)gx, B), 256, 0, s>>>(x, offsets, T, C, c_pad, static_cast<float*>(out));
+        pack_rows_kernel<float><<<dim3((unsigned)gx, B), 256, 0, s>>>(x, offsets, T, C, c_pad, static_cast<float*>(out), un_scale, un_shift);
     return hipGetLastError();
 }
 
 // flat[u*T_in + t][ld] -> y[u][t][0..C) for t < T_out
+// scale / shift (or nullptr): this layer's folded BatchNorm, applied here in fp32 (plain bf16 stores relu outputs)
 template <typename TI>
 __global__ void unpack_rows_kernel(const TI* __restrict__ flat, int ld, int T_in, int T_out, int C,
-                                   float* __restrict__ y) {
+                                   float* __restrict__ y, const float* __restrict__ scale, const float* __restrict__ shift) {
     const int u = blockIdx.y;
     const int64_t total = (int64_t)T_out * C;
     const TI* src = flat + (int64_t)u * T_in * ld;
@@ -217,7 +262,8 @@ __global__ void unpack_rows_kernel(const TI* __restrict__ flat, int ld, int T_in
          i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t t = i / C;
         const int c = (int)(i % C);
-        dst[i] = (float)src[t * ld + c];
+        const float v = (float)src[t * ld + c];
+        dst[i] = scale ? fmaf(v, scale[c], shift[c]) : v;
     }
 }
 
@@ -247,15 +293,15 @@ hipError_t launch_unpack_rows_split(const void* flat, int64_t plane_elems, int l
 }
 
 hipError_t launch_unpack_rows(const void* flat, bool in_bf16, int ld, int B, int T_in, int T_out, int C, float* y,
-                              hipStream_t s) {
+                              hipStream_t s, const float* scale, const float* shift) {
     if (B <= 0 || T_out <= 0) return hipSuccess;
     const int64_t per = (int64_t)T_out * C;
     int gx = (int)((per + 255) / 256);
     if (gx > 64) gx = 64;
     if (in_bf16)
-        unpack_rows_kernel<__bf16><<<dim3((unsigned)gx, B), 256, 0, s>>>(static_cast<const __bf16*>(flat), ld, T_in, T_out, C, y);
+        unpack_rows_kernel<__bf16><<<dim3((unsigned)gx, B), 256, 0, s>>>(static_cast<const __bf16*>(flat), ld, T_in, T_out, C, y, scale, shift);
     else
-        unpack_rows_kernel<float><<<dim3((unsigned)gx, B), 256, 0, s>>>(static_cast<const float*>(flat), ld, T_in, T_out, C, y);
+        unpack_rows_kernel<float><<<dim3((unsigned)gx, B), 256, 0, s>>>(static_cast<const float*>(flat), ld, T_in, T_out, C, y, scale, shift);
     return hipGetLastError();
 }
 

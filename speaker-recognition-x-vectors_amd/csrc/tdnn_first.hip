@@ -156,14 +156,9 @@ __global__ __launch_bounds__(256, 2) void tdnn_first_kernel(const TdnnArgs a) {
 
     const char* frag = smem + r * kRowB + 16 * h;  // A operand of lane (r, h): frame r, k = 16*ks + 8*h ..+7
     // epilogue constants of this lane's four channels (pair p: 128*wave + 64*p + 2r, +1)
-    float2 bi[2], sc[2], sh[2];
+    float2 bi[2];
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        const float* c0 = cst + 128 * wave + 64 * p + 2 * r;
-        bi[p] = *reinterpret_cast<const float2*>(c0);
-        sc[p] = *reinterpret_cast<const float2*>(c0 + 512);
-        sh[p] = *reinterpret_cast<const float2*>(c0 + 1024);
-    }
+    for (int p = 0; p < 2; ++p) bi[p] = *reinterpret_cast<const float2*>(cst + 128 * wave + 64 * p + 2 * r);
     // accumulator element e of lane (r, h): frame (e&3) + 8*(e>>2) + 4*h; the lane's dword sits at column 2r
     const int y_voff = (4 * h * a.ldy + 128 * wave + 2 * r) * 2;
     // __syncthreads() is `s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier`: it would hold every wave until its 32 stores
@@ -185,14 +180,14 @@ __global__ __launch_bounds__(256, 2) void tdnn_first_kernel(const TdnnArgs a) {
                                                                   __builtin_bit_cast(bf16x8, wf[cg][ks]), acc[cg], 0, 0, 0); \
         }                                                                                                         \
         if ((g_) + 1 < g_end) park(a, smem + ((buf_) ^ 1) * kTileB, rr, sks, ST_PARK);                     \
-        /* bias + ReLU + folded BatchNorm (tdnn_layer.py:30-39); rows of the group at g*32 (the row buffer is */  \
-        /* padded past the last valid frame) */                                                                   \
+        /* bias + ReLU (tdnn_layer.py:30-31; the BatchNorm behind it, :36-39, is deferred into layer 2's weights: */ \
+        /* xvec_api.hip, refold); rows of the group at g*32 (the row buffer is padded past the last valid frame) */ \
         const __amdgpu_buffer_rsrc_t yr = make_rsrc(static_cast<char*>(a.Y) + (g_) * 32 * (int64_t)a.ldy * 2);    \
         _Pragma("unroll") for (int p = 0; p < 2; ++p)                                                             \
             _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                                      \
-                const float v0 = fmaf(fmaxf(acc[2 * p][e] + bi[p].x, 0.f), sc[p].x, sh[p].x);                     \
-                const float v1 = fmaf(fmaxf(acc[2 * p + 1][e] + bi[p].y, 0.f), sc[p].y, sh[p].y);                 \
-                const unsigned pk = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{v0, v1}, bf16x2)); \
+                const float v0 = acc[2 * p][e] + bi[p].x, v1 = acc[2 * p + 1][e] + bi[p].y;                        \
+                unsigned pk = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{v0, v1}, bf16x2));       \
+                asm("v_pk_max_i16 %0, %1, 0" : "=v"(pk) : "v"(pk));   /* ReLU of the packed pair (tdnn_pp16.hip, relu_pk_bf16) */ \
                 __builtin_amdgcn_raw_buffer_store_b32(pk, yr, y_voff, (((e & 3) + 8 * (e >> 2)) * a.ldy + 64 * p) * 2, 0); \
             }                                                                                                     \
         XF_LDS_BARRIER() /* the other tile is written, this one read by every wave */                            \

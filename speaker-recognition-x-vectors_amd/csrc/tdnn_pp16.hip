@@ -138,13 +138,21 @@ __device__ unsigned long long g_pp16_clk[8];               // block 0: s_memtime
 //   bit 2: no epilogue (stores / pooling)
 #define PP_KNOCK_DMA ((XVEC_KNOCK & 1) != 0)
 #define PP_KNOCK_RD ((XVEC_KNOCK & 2) != 0)
-#define PP_KNOCK_EPI ((XVEC_KNOCK & 4) != 0)
+#define PP_KNOCK_EPI ((XVEC_KNOCK & 4) != 0 || ((XVEC_KNOCK & 2048) != 0 && POOL))   // bit 11: no epilogue in the pooling variant only (layers 2-4 keep theirs, so layer 5 still runs on real data)
 #define PP_KNOCK_RDW ((XVEC_KNOCK & 8) != 0)     // bit 3: no W fragment reads only
 #define PP_KNOCK_RDA ((XVEC_KNOCK & 16) != 0)    // bit 4: no A fragment reads only
 #define PP_KNOCK_MASKED ((XVEC_KNOCK & 32) != 0) // bit 5: pooling epilogue without its masked path (code-size experiment)
 #define PP_KNOCK_PARK ((XVEC_KNOCK & 64) != 0)   // bit 6: pooling epilogue without the LDS round trip of the running sums
 #define PP_KNOCK_ROWS ((XVEC_KNOCK & 128) != 0)  // bit 7: pooling epilogue on acc row 0 only
+#define PP_KNOCK_MXMF ((XVEC_KNOCK & 256) != 0)  // bit 8: matrix-pipe pooling without its MFMAs
+#define PP_KNOCK_MXPK ((XVEC_KNOCK & 512) != 0)  // bit 9: ... without the packing (max / cvt / mask) of the deviations
+#define PP_KNOCK_MXROWS ((XVEC_KNOCK & 1024) != 0) // bit 10: ... without the groups (restore / fold / park only)
+#define PP_KNOCK_MXFOLD ((XVEC_KNOCK & 4096) != 0) // bit 12: ... without the fold + park at the end of a tile
 #else
+#define PP_KNOCK_MXFOLD false
+#define PP_KNOCK_MXMF false
+#define PP_KNOCK_MXPK false
+#define PP_KNOCK_MXROWS false
 #define PP_KNOCK_MASKED false
 #define PP_KNOCK_PARK false
 #define PP_KNOCK_ROWS false
@@ -514,6 +522,14 @@ __device__ __forceinline__ float relu1(float x) {
     return r;
 }
 
+// ReLU of two packed bf16 values in ONE instruction: as 16-bit integers, negative floats (and -0) are negative and everything
+// else keeps its order, so max(x, 0) per half is the ReLU.  (A NaN with the sign bit set gives 0, one without stays a NaN.)
+__device__ __forceinline__ unsigned relu_pk_bf16(unsigned pk) {
+    unsigned r;
+    asm("v_pk_max_i16 %0, %1, 0" : "=v"(r) : "v"(pk));
+    return r;
+}
+
 // --- cross-lane helpers for the 16x16 accumulator layout (frames on the four lane quads q = l >> 4) --------------
 // {a summed over the two lane halves | b summed over the two lane halves}: v_permlane32_swap(a, b) returns
 // {a.lo | b.lo, a.hi | b.hi}; their sum holds a's total in the lower half and b's in the upper half
@@ -676,6 +692,225 @@ __device__ __forceinline__ void pool_finish(const TdnnArgs& a, int64_t limit, in
     }
 }
 
+
+// ---- fused statistics pooling of PLAIN bf16 (POOL && !X3): the sums on the matrix pipe ---------------------------------
+// The pooling epilogue above costs four vector instructions per value (ReLU, r - K, S1 +=, S2 fma) on both waves of every
+// SIMD, with the matrix pipe idle, and ~25 KB of code per tile height (the kernel: 111 KB, beyond the instruction cache).
+// bf16x3 keeps it (its partials must hold fp32-level sums).  Plain bf16 (bar 1e-2) does this instead:
+//   * ONE pivot C per (wave, channel) for the whole block: the ReLU output of the first frame of the wave's first tile,
+//     rounded to bf16.  From the block's second tile on it is inside the accumulators already -- their first MFMA takes
+//     bias - C as srcC (PP_MF_S0) -- so a deviation is ONE instruction:  d = r - C = max(z + bias - C, -C).  (The first tile
+//     subtracts C once it knows it.)  Every partial of the wave carries K = C: pool_finalize_seg re-bases in fp64.
+//   * the deviations of a 32-frame group, rounded to bf16 and packed (8 per lane: frames 16 f + 4 q + e of the lane's channel
+//     of channel block cb), are at once the B operand [32 frames x 16 channels] and the A operand [16 channels x 32 frames]
+//     of a 16x16x32 MFMA:   ones x d = S1 in every row,   d^T x d = the Gram matrix, whose DIAGONAL is S2
+//     (lane c + 16 (c >> 2), register c & 3).  Two MFMAs per channel block and group replace 96 vector instructions.
+//   * why bf16 deviations are enough: d is small where it matters (|mean - C| is a few std: C is a sample of the channel),
+//     each product is exact in the fp32 accumulator, and rounding d costs 2^-9 |d| of RANDOM error per frame (2e-4 of a
+//     std on a mean over 286 frames); C itself is bf16-exact so that the frames where the channel is off (d = -C, all
+//     alike) round with no error at all instead of a common one.
+//   * rows outside the segment (another utterance, another block, past the batch) are cleared in the PACKED operand with a
+//     bit mask (v_and: garbage, NaN included, becomes +0 in both operands).
+// Between epilogues a wave parks C | S1 | S2 compactly (48 B per lane, as before); the MFMA accumulators restart at zero.
+struct SegMx {
+    f32x4 c;                    // pivot of the lane's four channels (bf16-exact)
+    f32x4 a01, a23;             // S1 accumulators, two channel blocks each: blocks 0 / 2 in the even rows (registers 0, 2), blocks 1 / 3 in
+                                // the odd ones -- their MFMAs take `ones` only in the even / odd ROWS of the A operand (lanes): half the registers
+    f32x4 g0, g1, g2, g3;       // Gram accumulators
+    // the lane's 48 bytes of LDS at park_base + 48 * lane: C | S1 | S2, the compact sums gathered before the last fold (needed at
+    // a fold only: in registers they were 8 of the ~20 the epilogue spilled).  Everything lane-derived a fold or a flush needs
+    // (its LDS slot, lane quad q, row r, first column) is recomputed THERE from an opaque lane id: computed once per epilogue
+    // the compiler holds it in registers across the groups, and the epilogue has none to spare.
+    char* park_base;            // wave-uniform: smem + kParkOff + 48 * 64 * wave
+    int colw;                   // wave-uniform: first column of the wave, n0 + 64 * wc
+    bool cnt_wave;              // wave-uniform: this wave's lane 0 writes the frame counts (first column block, first wave column)
+};
+__device__ __forceinline__ int mx_lane() {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
+
+__device__ __forceinline__ unsigned pk_min_u16(unsigned x, unsigned y) {
+    unsigned r;
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+}
+__device__ __forceinline__ unsigned cvt_pk(float x, float y) {
+    typedef float f32x2v __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{x, y}, bf16x2));
+}
+
+// The pooling MFMAs are inline asm with the accumulator TIED, like the K loop's (PP_MF): with the builtin hipcc gave every
+// MFMA a fresh destination and copied the 32 accumulator registers at every merge of the bookkeeping's control flow -- 160
+// v_mov per 32-frame group next to 56 useful instructions (stamps: 1.4-2.0 k cycles per group, no better than the vector sums
+// they replaced).  What hipcc would otherwise look after is looked after by hand, and so that it holds WHATEVER copies the
+// register allocator still places around the asm statements (it does, where paths merge):
+//   * vector write -> MFMA operand read: every MFMA pair is ONE asm statement that opens with two wait states (s_nop 1),
+//     so a copy or a mask the compiler puts in front of the statement is two wait states old when the MFMA reads it;
+//   * MFMA write -> vector read (4 passes: 7 wait states): PMX_SETTLE() closes every group, PP_MFMA_SETTLE() every fold;
+//   * the same accumulator in two MFMAs of a group (a01 / a23): a dependent chain, interlocked by the hardware like the
+//     K loop's.
+// ONE code path per group: a whole group runs the masked form with an all-ones mask (16 more v_and per group and wave, but
+// no second copy of the group's code and no merge of two register assignments of the accumulators).
+#define PMX_MFS(pk_, ONES_, A_, G_)                                                                            \
+    if constexpr (PP_KNOCK_MXMF) asm volatile("" : "+v"(A_), "+v"(G_) : "v"(ONES_), "v"(pk_)); else                 \
+    asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %2, %3, %0\n\tv_mfma_f32_16x16x32_bf16 %1, %3, %3, %1"     \
+                 : "+v"(A_), "+v"(G_) : "v"(ONES_), "v"(pk_));
+#define PMX_SETTLE() asm volatile("s_nop 7" ::: "memory")
+
+// what the MFMA accumulators gathered goes to the compact sums; they restart at zero
+__device__ __forceinline__ void fold_mx(SegMx& sg) {
+    PP_MFMA_SETTLE();
+    const int lane = mx_lane(), r = lane & 15;
+    char* park = sg.park_base + lane * 48;
+    // the diagonal element of the lane: register r & 3, taken with three selects on two bit tests (written as a chain of
+    // `k == j ? g[j]` hipcc turns it into a vector element at a run-time index -- through scratch memory)
+    const bool b0 = (r & 1) != 0, b1 = (r & 2) != 0;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#define PMX_DIAG(g_) (b1 ? (b0 ? g_[3] : g_[2]) : (b0 ? g_[1] : g_[0]))
+    f32x4 s1 = *reinterpret_cast<const f32x4*>(park + 16), s2 = *reinterpret_cast<const f32x4*>(park + 32);
+    s1[0] += sg.a01[0]; s1[1] += sg.a01[1]; s1[2] += sg.a23[0]; s1[3] += sg.a23[1];
+    s2[0] += PMX_DIAG(sg.g0); s2[1] += PMX_DIAG(sg.g1); s2[2] += PMX_DIAG(sg.g2); s2[3] += PMX_DIAG(sg.g3);
+    *reinterpret_cast<f32x4*>(park + 16) = s1;
+    *reinterpret_cast<f32x4*>(park + 32) = s2;
+#undef PMX_DIAG
+    sg.a01 = z; sg.a23 = z;
+    sg.g0 = z; sg.g1 = z; sg.g2 = z; sg.g3 = z;
+    // (the zeros are vector writes of registers the next MFMAs read as srcC: they come a group's packing later at the earliest)
+    asm volatile("" : "+v"(sg.a01), "+v"(sg.a23));
+    asm volatile("" : "+v"(sg.g0), "+v"(sg.g1), "+v"(sg.g2), "+v"(sg.g3));
+}
+
+// write the segment's partial (slot layout: tdnn_common.h, three planes K | S1 | S2): the 16 lanes that hold the Gram
+// diagonals (q == r >> 2) own four adjacent channels each -- three 16-byte stores, 256 contiguous bytes per plane
+__device__ __forceinline__ void flush_mx(const TdnnArgs& a, SegMx& sg, int slot, int n_rows) {
+    fold_mx(sg);
+    const int lane = mx_lane(), q = lane >> 4, r = lane & 15;
+    char* park = sg.park_base + lane * 48;
+    const int col0 = sg.colw + 4 * r;
+    const int ld = a.ldy;
+    const __amdgpu_buffer_rsrc_t prs = make_rsrc(a.pool_part + (int64_t)slot * (kPoolPlanes * ld));
+    if (q == (r >> 2)) {
+        const u32x4 kv = __builtin_bit_cast(u32x4, sg.c), v1 = *reinterpret_cast<const u32x4*>(park + 16),
+                    v2 = *reinterpret_cast<const u32x4*>(park + 32);
+        __builtin_amdgcn_raw_buffer_store_b128(kv, prs, col0 * 4, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(v1, prs, (col0 + ld) * 4, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(v2, prs, (col0 + 2 * ld) * 4, 0, 0);
+        asm volatile("s_nop 1" ::"v"(kv), "v"(v1), "v"(v2));       // the 128-bit-store data hazard (tdnn_common.h, store_acc)
+    }
+    if (sg.cnt_wave && lane == 0) a.pool_cnt[slot] = n_rows;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    *reinterpret_cast<f32x4*>(park + 16) = z;
+    *reinterpret_cast<f32x4*>(park + 32) = z;
+}
+
+// first compact row of utterance u, fixed-length or ragged decided at RUN time by a scalar branch (the offsets through the
+// scalar cache: sload_i64): one copy of the epilogue instead of two
+__device__ __forceinline__ int64_t first_row_rt(const RowMap& m, int u) {
+    u = __builtin_amdgcn_readfirstlane(u);
+    if (m.offsets != nullptr) return sload_i64(m.offsets + u) - (int64_t)u * m.cum;
+    return (int64_t)u * (m.fixed_T - m.cum);
+}
+
+// cursor of the matrix-pipe form: SegCur plus the end of the current utterance RELATIVE to the wave's first row of the tile,
+// clamped to 32 bits -- the per-group bookkeeping is then 32-bit scalar arithmetic (a 64-bit compare is a vector instruction
+// and a round trip through vcc on this ISA)
+__device__ __forceinline__ int rel_row(int64_t row, int64_t base) {
+    const int64_t d = row - base;
+    return (int)(d < -(1 << 30) ? -(1 << 30) : d > (1 << 30) ? (1 << 30) : d);
+}
+
+// packed deviations of channel block cb_ of one 32-frame group: v0 / v1 = its accumulators of frame blocks 0 / 1 (z + bias - C).
+// d = max(z + bias - C, -C) is taken AFTER the rounding, on the packed pair: -C is bf16-exact, so the two commute, and as
+// unsigned 16-bit patterns the larger of a bf16 x and a bf16 m <= 0 is their MINIMUM (a positive x is below 0x8000 <= m; of two
+// negative values the smaller pattern is the smaller magnitude) -- one v_pk_min_u16 per pair instead of two v_max_f32.  The same
+// instruction masks: where a frame lies outside the segment the operand's half is 0x0000, and min(x, 0) = +0 whatever x holds.
+#define PMX_PACKM(pk_, cb_, v0_, v1_)                                                                          \
+    u32x4 pk_ = ones_e;                                                                                        \
+    if constexpr (!PP_KNOCK_MXPK) {                                                                            \
+        const u32x4 m_ = mk & ncp[cb_];                                                                        \
+        pk_ = u32x4{pk_min_u16(cvt_pk(v0_[0], v0_[1]), m_[0]), pk_min_u16(cvt_pk(v0_[2], v0_[3]), m_[1]),      \
+                    pk_min_u16(cvt_pk(v1_[0], v1_[1]), m_[2]), pk_min_u16(cvt_pk(v1_[2], v1_[3]), m_[3])};     \
+    }
+#define PMX_GROUP()                                                                                            \
+    {                                                                                                          \
+        PMX_PACKM(pk0, 0, v00, v10) SB();                                                                      \
+        PMX_PACKM(pk1, 1, v01, v11) SB();                                                                      \
+        PMX_MFS(pk0, ones_e, sg.a01, sg.g0) SB();                                                              \
+        PMX_PACKM(pk2, 2, v02, v12) SB();                                                                      \
+        PMX_MFS(pk1, ones_o, sg.a01, sg.g1) SB();                                                              \
+        PMX_PACKM(pk3, 3, v03, v13) SB();                                                                      \
+        PMX_MFS(pk2, ones_e, sg.a23, sg.g2) SB();                                                              \
+        PMX_MFS(pk3, ones_o, sg.a23, sg.g3) SB();                                                              \
+        PMX_SETTLE(); SB();                                                                                    \
+    }
+
+// One 32-frame group of this wave (acc row): v{f}{cb} = accumulator of frame block f and channel block cb, holding
+// z + bias - C.  g0 = the group's first row relative to the wave's first row of the tile, lim_rel = first row (relative) that
+// is not this block's, sc.end_rel likewise the end of the current utterance.
+struct SegCurMx {
+    int u, n;
+    int64_t end;
+    int end_rel;
+};
+__device__ __forceinline__ void pool_rows_mx(const TdnnArgs& a, const f32x4& v00, const f32x4& v01, const f32x4& v02,
+                                             const f32x4& v03, const f32x4& v10, const f32x4& v11, const f32x4& v12,
+                                             const f32x4& v13, int g0, int lim_rel, int64_t row_base, int blk, int grp, SegCurMx& sc,
+                                             SegMx& sg, const u32x4& ones_e, const u32x4& ones_o) {
+    // -C of the lane's four channels as packed bf16 pairs (C is bf16-exact: the upper half of its fp32 pattern, sign flipped)
+    const u32x4 cb_ = __builtin_bit_cast(u32x4, sg.c);
+    const u32x4 ncp = {((cb_[0] ^ 0x80000000u) >> 16) * 0x10001u, ((cb_[1] ^ 0x80000000u) >> 16) * 0x10001u,
+                       ((cb_[2] ^ 0x80000000u) >> 16) * 0x10001u, ((cb_[3] ^ 0x80000000u) >> 16) * 0x10001u};
+    const RowMap& m = a.out_map;
+    if (g0 >= lim_rel) return;
+    const int n_last = m.n_utts - 1;
+    const int g_end = g0 + 32 < lim_rel ? g0 + 32 : lim_rel;
+#define PMX_NEXT_UTT()                                                                                         \
+    {                                                                                                          \
+        flush_mx(a, sg, 2 * (blk + sc.u) + grp, sc.n);                                                         \
+        sc.u = __builtin_amdgcn_readfirstlane(sc.u + 1);                                                       \
+        sc.n = 0;                                                                                              \
+        sc.end = first_row_rt(m, sc.u + 1);                                                                    \
+        sc.end_rel = rel_row(sc.end, row_base);                                                                \
+    }
+    // utterances that ended before this group (the current one, and any that lay wholly in the other group's rows)
+    while (sc.end_rel <= g0 && sc.u < n_last) PMX_NEXT_UTT()
+    int lo = g0;
+    for (;;) {
+        const int hi = sc.end_rel < g_end ? sc.end_rel : g_end;       // rows [lo, hi) of the group belong to sc.u
+        if (hi > lo) {
+            {
+                const int lo_l = lo - g0, hi_l = hi - g0;             // local rows [lo_l, hi_l) of the group
+                const unsigned below_hi = hi_l >= 32 ? 0xffffffffu : ((1u << hi_l) - 1u);
+                const unsigned lm = (below_hi & ~((1u << lo_l) - 1u)) >> (4 * (mx_lane() >> 4));   // this lane's frames (lane quad q): bit 16 f + e
+                // packed register j holds frames (f, e) = (j >> 1, 2 (j & 1)) in its low half and (j >> 1, 2 (j & 1) + 1) in its high half
+#define PMX_MK(b_) ((unsigned)(-(int)((lm >> (b_)) & 1u)) & 0xffffu) | ((unsigned)(-(int)((lm >> ((b_) + 1)) & 1u)) << 16)
+                const u32x4 mk = {PMX_MK(0), PMX_MK(2), PMX_MK(16), PMX_MK(18)};
+#undef PMX_MK
+                PMX_GROUP()
+            }
+            sc.n += hi - lo;
+        }
+        if (sc.end_rel >= g_end || sc.u >= n_last) break;            // the utterance goes on past this group
+        PMX_NEXT_UTT()                                                // it ended inside the group
+        lo = hi;
+    }
+#undef PMX_NEXT_UTT
+}
+
+// end of the block (pool_finish for this form)
+__device__ __forceinline__ void pool_finish_mx(const TdnnArgs& a, int64_t limit, int blk, int grp, SegCurMx& sc, SegMx& sg) {
+    const RowMap& m = a.out_map;
+    for (;;) {
+        flush_mx(a, sg, 2 * (blk + sc.u) + grp, sc.n);
+        sc.n = 0;
+        if (sc.u >= m.n_utts - 1 || sc.end >= limit) break;
+        sc.u = __builtin_amdgcn_readfirstlane(sc.u + 1);
+        sc.end = first_row_rt(m, sc.u + 1);
+    }
+}
+
 // One tile: K loop, request of the next tile's first K-tiles, epilogue.
 template <int MR, bool POOL, bool X3>
 __device__ __forceinline__ void process_tile(const TdnnArgs& a, char* smem, Stream& st, const Lane& ln,
@@ -693,7 +928,13 @@ __device__ __forceinline__ void process_tile(const TdnnArgs& a, char* smem, Stre
     // the bias of the lane's four channels, one four-register tuple per channel block: srcC of every accumulator's first MFMA
     f32x4 bias4_0, bias4_1, bias4_2, bias4_3;
     {
-        const float4 bi = *reinterpret_cast<const float4*>(cst);
+        float4 bi = *reinterpret_cast<const float4*>(cst);
+        if constexpr (POOL && !X3) {    // matrix-pipe pooling: the block's pivot C rides in the accumulators (0 in the first tile)
+            int lane_p;       // opaque lane id: from ln.* the address is hoisted out of the tile loop and held (spilled) across it
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_p));
+            const f32x4 cp = *reinterpret_cast<const f32x4*>(smem + kParkOff + (ln.wave * 64 + lane_p) * 48);
+            bi.x -= cp[0]; bi.y -= cp[1]; bi.z -= cp[2]; bi.w -= cp[3];
+        }
         bias4_0 = f32x4{bi.x, bi.x, bi.x, bi.x};
         bias4_1 = f32x4{bi.y, bi.y, bi.y, bi.y};
         bias4_2 = f32x4{bi.z, bi.z, bi.z, bi.z};
@@ -796,21 +1037,31 @@ __device__ __forceinline__ void process_tile(const TdnnArgs& a, char* smem, Stre
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
         const int y_voff = (4 * (lane_e >> 4) * a.ldy + ln.wc * 64 + 4 * (lane_e & 15)) * 2;
         const float* cst_e = reinterpret_cast<const float*>(smem + kConstOff) + ln.wc * 64 + 4 * (lane_e & 15);
-        const float4 sc = *reinterpret_cast<const float4*>(cst_e + 256), sh = *reinterpret_cast<const float4*>(cst_e + 512);
-        float4 bi_e = make_float4(0.f, 0.f, 0.f, 0.f);           // bf16x3: the bias is not in the accumulators (PP_MF_S0)
-        if constexpr (X3) bi_e = *reinterpret_cast<const float4*>(cst_e);
-#define PP_BZ(v_, b_) (X3 ? (v_) + (b_) : (v_))
+        // bf16x3 only: scale / shift of the folded BatchNorm and the bias (not in its accumulators, PP_MF_S0).  Plain bf16 stores
+        // relu(z + bias') and nothing else: its BatchNorm is deferred into the consumer's weights (xvec_api.hip, refold), the
+        // bias is in the accumulators, and the ReLU is taken on the PACKED pair (relu_pk_bf16: one instruction per two values):
+        // 1.25 vector instructions per value instead of 2.75, in an epilogue that runs in the open on both waves of a SIMD.
+        float4 sc = make_float4(0.f, 0.f, 0.f, 0.f), sh = sc, bi_e = sc;
+        if constexpr (X3) {
+            sc = *reinterpret_cast<const float4*>(cst_e + 256);
+            sh = *reinterpret_cast<const float4*>(cst_e + 512);
+            bi_e = *reinterpret_cast<const float4*>(cst_e);
+        }
 #define PP_STORE_F(i_, f_)                                                                             \
             _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                               \
-                const float v0 = fmaf(relu1(PP_BZ(acc##i_##f_##0[e], bi_e.x)), sc.x, sh.x);          \
-                const float v1 = fmaf(relu1(PP_BZ(acc##i_##f_##1[e], bi_e.y)), sc.y, sh.y);          \
-                const float v2 = fmaf(relu1(PP_BZ(acc##i_##f_##2[e], bi_e.z)), sc.z, sh.z);          \
-                const float v3 = fmaf(relu1(PP_BZ(acc##i_##f_##3[e], bi_e.w)), sc.w, sh.w);          \
-                const u32x2 pk = {__builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{v0, v1}, bf16x2)), \
-                                  __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{v2, v3}, bf16x2))}; \
                 const int so_ = (ln.grp * 32 * MR + 32 * i_ + 16 * f_ + e) * a.ldy * 2;                   \
-                __builtin_amdgcn_raw_buffer_store_b64(pk, yrsrc, y_voff, so_, 0);                         \
-                if constexpr (X3) {   /* the remainders v - hi go to the lo plane, y_plane_bytes further on */ \
+                if constexpr (!X3) {                                                                      \
+                    const u32x2 pk = {relu_pk_bf16(__builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{acc##i_##f_##0[e], acc##i_##f_##1[e]}, bf16x2))), \
+                                      relu_pk_bf16(__builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{acc##i_##f_##2[e], acc##i_##f_##3[e]}, bf16x2)))}; \
+                    __builtin_amdgcn_raw_buffer_store_b64(pk, yrsrc, y_voff, so_, 0);                     \
+                } else {   /* ReLU + folded BatchNorm, then hi and the remainder v - hi (lo plane, y_plane_bytes further on) */ \
+                    const float v0 = fmaf(relu1(acc##i_##f_##0[e] + bi_e.x), sc.x, sh.x);                 \
+                    const float v1 = fmaf(relu1(acc##i_##f_##1[e] + bi_e.y), sc.y, sh.y);                 \
+                    const float v2 = fmaf(relu1(acc##i_##f_##2[e] + bi_e.z), sc.z, sh.z);                 \
+                    const float v3 = fmaf(relu1(acc##i_##f_##3[e] + bi_e.w), sc.w, sh.w);                 \
+                    const u32x2 pk = {__builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{v0, v1}, bf16x2)), \
+                                      __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{v2, v3}, bf16x2))}; \
+                    __builtin_amdgcn_raw_buffer_store_b64(pk, yrsrc, y_voff, so_, 0);                     \
                     const float l0 = v0 - __uint_as_float(pk[0] << 16), l1 = v1 - __uint_as_float(pk[0] & 0xffff0000u); \
                     const float l2 = v2 - __uint_as_float(pk[1] << 16), l3 = v3 - __uint_as_float(pk[1] & 0xffff0000u); \
                     const u32x2 pl = {__builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{l0, l1}, bf16x2)), \
@@ -823,7 +1074,54 @@ __device__ __forceinline__ void process_tile(const TdnnArgs& a, char* smem, Stre
         PP_STORE(0) PP_STORE(1) PP_STORE(2) PP_STORE(3)
 #undef PP_STORE
 #undef PP_STORE_F
-#undef PP_BZ
+    } else if constexpr (!X3) {
+        // plain bf16: the pooling sums on the matrix pipe (SegMx above)
+        SegMx sg;
+        sg.park_base = smem + kParkOff + ln.wave * (64 * 48);
+        sg.colw = n0 + ln.wc * 64;
+        sg.cnt_wave = n0 == 0 && ln.wc == 0;
+        sg.c = *reinterpret_cast<const f32x4*>(sg.park_base + mx_lane() * 48);
+        sg.a01 = f32x4{0.f, 0.f, 0.f, 0.f};
+        sg.a23 = sg.a01;
+        sg.g0 = sg.a01; sg.g1 = sg.a01; sg.g2 = sg.a01; sg.g3 = sg.a01;
+        asm volatile("" : "+v"(sg.a01), "+v"(sg.a23));                                 // written here, not sunk to the first MFMA
+        asm volatile("" : "+v"(sg.g0), "+v"(sg.g1), "+v"(sg.g2), "+v"(sg.g3));
+        if (first && row0 < limit) {
+            // the block's first tile: its accumulators hold z + bias (C was 0).  C = relu of the group's first frame (quad 0,
+            // register 0 of frame block 0), rounded to bf16 so that -C is exact in the packed operand; subtracted here, ONCE
+#define PP_PIV(c_) __uint_as_float(__float_as_uint(quad0(relu1(acc00##c_[0]))) + 0x8000u & 0xffff0000u)
+            sg.c = f32x4{PP_PIV(0), PP_PIV(1), PP_PIV(2), PP_PIV(3)};
+#undef PP_PIV
+#define PP_SUBC(i_) if (MR > i_) { acc##i_##00 -= sg.c[0]; acc##i_##10 -= sg.c[0]; acc##i_##01 -= sg.c[1]; acc##i_##11 -= sg.c[1]; \
+                                   acc##i_##02 -= sg.c[2]; acc##i_##12 -= sg.c[2]; acc##i_##03 -= sg.c[3]; acc##i_##13 -= sg.c[3]; }
+            PP_SUBC(0) PP_SUBC(1) PP_SUBC(2) PP_SUBC(3)
+#undef PP_SUBC
+        }
+        // all wave-uniform row bookkeeping below is 32-bit, relative to the wave's first row of this tile
+        const int lim_rel = rel_row(limit, row0);
+        SegCurMx scm = {sc.u, sc.n, sc.end, rel_row(sc.end, row0)};
+        // A operands of the S1 MFMAs: bf16 ones in the even / the odd rows (row = lane & 15), zeros in the others
+        const unsigned one_e = (mx_lane() & 1) ? 0u : 0x3f803f80u, one_o = one_e ^ 0x3f803f80u;
+        u32x4 ones_e = {one_e, one_e, one_e, one_e}, ones_o = {one_o, one_o, one_o, one_o};
+        asm volatile("" : "+v"(ones_e), "+v"(ones_o));        // materialised here, well before the first MFMA reads them
+#define PP_POOLMX(i_)                                                                                  \
+        if (MR > i_ && !PP_KNOCK_MXROWS)                                                                  \
+            pool_rows_mx(a, acc##i_##00, acc##i_##01, acc##i_##02, acc##i_##03, acc##i_##10, acc##i_##11, acc##i_##12, \
+                         acc##i_##13, 32 * i_, lim_rel, row0, blk, ln.grp, scm, sg, ones_e, ones_o);
+        PP_ESTAMP(0)
+        PP_POOLMX(0) PP_ESTAMP(1) PP_POOLMX(1) PP_ESTAMP(2) PP_POOLMX(2) PP_ESTAMP(3) PP_POOLMX(3) PP_ESTAMP(4)
+#undef PP_POOLMX
+        if (!has_next) pool_finish_mx(a, limit, blk, ln.grp, scm, sg);
+        sc.u = scm.u;
+        sc.n = scm.n;
+        sc.end = scm.end;
+        if constexpr (!PP_KNOCK_MXFOLD) {
+            fold_mx(sg);
+            *reinterpret_cast<f32x4*>(sg.park_base + mx_lane() * 48) = sg.c;
+        } else {
+            asm volatile("" ::"v"(sg.a01), "v"(sg.a23), "v"(sg.g0), "v"(sg.g1), "v"(sg.g2), "v"(sg.g3), "v"(sg.c));
+        }
+        PP_ESTAMP(5)
     } else {
         // (lane-derived values of this epilogue come from an opaque lane id: computed from ln.* the compiler hoists them
         //  out of the tile loop and carries them through the K loop, which has no register to spare)

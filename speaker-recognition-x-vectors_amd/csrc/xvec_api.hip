@@ -74,6 +74,12 @@ struct xvec_handle {
     void* Wr48[XVEC_NUM_TDNN];         // bf16x3, K-tile major for tdnn_pp16.hip: per K-tile W_hi | W_lo | W_hi (3x the size of Wr16)
     float* Wp[XVEC_NUM_TDNN];
     float* vec[XVEC_NUM_TDNN];         // bias | scale | shift, n_pad each
+    // Plain bf16 DEFERS every layer's BatchNorm into its consumer (refold below): layer l stores relu(z + bias'), layer l+1's
+    // bf16 weights carry scale_l and its bias' the shift_l (layer 5's BatchNorm goes to pool_finalize as in every mode).
+    float* Wraw[XVEC_NUM_TDNN];        // the caller's fp32 weight [cout][taps*cin] and bias, kept for re-folding when the
+    float* braw[XVEC_NUM_TDNN];        // producing layer's BatchNorm is (re)loaded later
+    float* vec16[XVEC_NUM_TDNN];       // bias' | 1 | 0 (n_pad each): epilogue constants of the plain-bf16 kernels
+    bool folded[XVEC_NUM_TDNN];        // Wp16 / Wr16 / vec16 of the layer are consistent with the producing layer's BatchNorm
     bool tdnn_loaded[XVEC_NUM_TDNN];
     float* affW[3];
     float* affB[3];
@@ -88,8 +94,6 @@ struct xvec_handle {
     int offs_next;
     int num_cu;
     int blocks_per_cu;                 // persistent TDNN blocks per CU (LDS allows 2)
-    int64_t pool_units;                // geometry of the last tdnn_pp launch (pool_finalize's segment form needs it)
-    int pool_bpc;
     int last_kernel[XVEC_NUM_TDNN];    // XVEC_KERNEL_* the last launch of each frame-level layer went to (xvec_get_dispatch)
     // profiling
     bool profiling;
@@ -190,12 +194,23 @@ int pp_blocks_per_col(const xvec_handle* h, int n_pad, int64_t rows_out) {
     return (bpc >= 1 && units >= bpc && 10 * units >= h->pp_min_tenths * (int64_t)bpc) ? bpc : 0;
 }
 
+// What run_tdnn launched: kernel family and, for the large-batch mapping, the geometry its pooling partials were written
+// with.  Returned to the caller and handed to finalize_pool explicitly (taken from handle state it was right only
+// as long as layer 5 happened to be the last launch before the finalize, on the one thread using the handle).
+struct Dispatch {
+    int kernel = XVEC_KERNEL_NONE;
+    int64_t pool_units = 0;
+    int pool_bpc = 0;
+};
+
 // Launch one frame-level layer on flat rows.  The variant selects arithmetic and epilogue; bf16
 // variants use the bf16 packing (64-element chunks) of the layer's weights.
 // x3: bf16x3 arithmetic -- X (and Y, when it is bf16) are two bf16 planes `x_plane` / `y_plane` bytes apart
 int run_tdnn(xvec_handle* h, int layer, TdnnVariant v, const void* X, int ldx, int64_t x_rows, void* Y,
              int64_t rows_out, const RowMap& out_map, float* part, hipStream_t s, bool x3 = false,
-             int64_t x_plane = 0, int64_t y_plane = 0, int* part_cnt = nullptr) {
+             int64_t x_plane = 0, int64_t y_plane = 0, int* part_cnt = nullptr, Dispatch* disp = nullptr) {
+    Dispatch d_local;
+    Dispatch& d = disp ? *disp : d_local;
     const bool in16 = v == TdnnVariant::kBf16 || v == TdnnVariant::kBf16Pool || v == TdnnVariant::kBf16ToF32 ||
                       v == TdnnVariant::kBf16First || v == TdnnVariant::kBf16FirstToF32 || v == TdnnVariant::kBf16FirstSrc32;
     const TdnnGeom& g = in16 ? h->geo16[layer] : h->geo[layer];
@@ -204,9 +219,11 @@ int run_tdnn(xvec_handle* h, int layer, TdnnVariant v, const void* X, int ldx, i
     a.X = X;
     a.W = h->Wp[layer];
     a.Wf = h->Wp16[layer];
-    a.bias = h->vec[layer];
-    a.scale = h->vec[layer] + g.n_pad;
-    a.shift = h->vec[layer] + 2 * g.n_pad;
+    // plain bf16: the folded constants (bias', 1, 0) -- BatchNorm is deferred into the consumer's weights (refold)
+    const float* vecs = (in16 && !x3) ? h->vec16[layer] : h->vec[layer];
+    a.bias = vecs;
+    a.scale = vecs + g.n_pad;
+    a.shift = vecs + 2 * g.n_pad;
     a.Y = Y;
     a.x_rows = x_rows;
     a.ldx = ldx;
@@ -240,12 +257,12 @@ int run_tdnn(xvec_handle* h, int layer, TdnnVariant v, const void* X, int ldx, i
         const int64_t es = (in16 && v != TdnnVariant::kBf16FirstSrc32) ? 2 : 4;   // element size of the rows READ
         const int64_t reach = ((int64_t)out_map.n_utts * a.span + kRowPadTail) * ldx * es + (x3 ? x_plane : 0);
         if (reach > 0x7fffffff)
-            return fail(XVEC_ERR_ARG, "layer %d: %d utterances x %d channels exceed 32-bit row offsets; split the batch",
+            return fail(XVEC_ERR_TOO_LARGE, "layer %d: %d utterances x %d channels exceed 32-bit row offsets; split the batch",
                         layer, out_map.n_utts, ldx);
     }
     if (x3) {
         if (x_plane > 0x3fffffff || y_plane > 0x3fffffff)
-            return fail(XVEC_ERR_ARG, "batch too large for bf16x3 (plane offsets must fit 30 bits); split it");
+            return fail(XVEC_ERR_TOO_LARGE, "batch too large for bf16x3 (plane offsets must fit 30 bits); split it");
         a.terms = 2;
         a.Wf = h->Wp48[layer];
         a.k_pad = 2 * g.k_pad;
@@ -266,10 +283,10 @@ int run_tdnn(xvec_handle* h, int layer, TdnnVariant v, const void* X, int ldx, i
             a.blocks_per_col = bpc;
             a.groups_total = units;
             a.pair_period = 0;
-            h->pool_units = units;
-            h->pool_bpc = bpc;
+            d.pool_units = units;
+            d.pool_bpc = bpc;
             HIP_TRY(launch_tdnn_pp16(a, v == TdnnVariant::kBf16Pool, s));
-            h->last_kernel[layer] = XVEC_KERNEL_PP;
+            h->last_kernel[layer] = d.kernel = XVEC_KERNEL_PP;
             return XVEC_OK;
         }
     }
@@ -277,26 +294,45 @@ int run_tdnn(xvec_handle* h, int layer, TdnnVariant v, const void* X, int ldx, i
         if (!(h->use_pp && layer == 0 && tdnn_first3_applicable(a)))
             return fail(XVEC_ERR_STATE, "internal: bf16x3 layer 1 from fp32 rows needs the streaming kernel's shapes");
         HIP_TRY(launch_tdnn_first3(a, h->num_cu, s));
-        h->last_kernel[layer] = XVEC_KERNEL_FIRST;
+        h->last_kernel[layer] = d.kernel = XVEC_KERNEL_FIRST;
         return XVEC_OK;
     }
     if (h->use_pp && layer == 0 && v == TdnnVariant::kBf16FirstSrc32 && tdnn_first_applicable(a)) {
         HIP_TRY(launch_tdnn_first(a, h->num_cu, s));
-        h->last_kernel[layer] = XVEC_KERNEL_FIRST;
+        h->last_kernel[layer] = d.kernel = XVEC_KERNEL_FIRST;
         return XVEC_OK;
     }
     // pooling partials of the 128x128 kernels: one slot per (32-row group, utterance), addressed with 32-bit offsets
     // (tdnn_pp16.hip's segment partials take a 64-bit base per slot and have no such limit)
     if (part && (size_t)((rows_out + 31) / 32 + out_map.n_utts + 1) * 3 * g.n_pad * 4 > 0x7fffffffull)
-        return fail(XVEC_ERR_ARG, "batch too large: pooling partials exceed 2 GiB; split it");
+        return fail(XVEC_ERR_TOO_LARGE, "batch too large: pooling partials exceed 2 GiB; split it");
     HIP_TRY(launch_tdnn(a, v, s));
-    h->last_kernel[layer] = XVEC_KERNEL_TILE128;
+    h->last_kernel[layer] = d.kernel = XVEC_KERNEL_TILE128;
+    return XVEC_OK;
+}
+
+// (Re)build the plain-bf16 copies of one layer: weights scaled per input channel by the PRODUCING layer's folded BatchNorm
+// scale, bias' = bias + W . shift_prev (reference order Linear -> ReLU -> BatchNorm, tdnn_layer.py:30-39: the BatchNorm of
+// layer l is an affine map of layer l+1's input, and the valid convolutions have no padded frames where that would differ).
+// Needs the layer itself and its producer loaded; xvec_load_tdnn calls it for the layer it loads and for its consumer.
+int refold(xvec_handle* h, int layer, hipStream_t s) {
+    if (layer < 0 || layer >= XVEC_NUM_TDNN || !h->tdnn_loaded[layer]) return XVEC_OK;
+    if (layer > 0 && !h->tdnn_loaded[layer - 1]) { h->folded[layer] = false; return XVEC_OK; }
+    const TdnnGeom& g = h->geo16[layer];
+    const float* sc = layer > 0 ? h->vec[layer - 1] + h->geo[layer - 1].n_pad : nullptr;
+    const float* sh = layer > 0 ? h->vec[layer - 1] + 2 * h->geo[layer - 1].n_pad : nullptr;
+    HIP_TRY(launch_pack_tdnn_bf16(h->Wraw[layer], sc, g, h->Wp16[layer], s));
+    HIP_TRY(launch_pack_tdnn_rows_bf16(h->Wraw[layer], sc, g, h->Wr16[layer], s));
+    HIP_TRY(launch_fold_bias(h->Wraw[layer], h->braw[layer], sh, g, h->vec16[layer], s));
+    h->folded[layer] = true;
     return XVEC_OK;
 }
 
 int check_loaded(const xvec_handle* h, int mode) {
     for (int i = 0; i < XVEC_NUM_TDNN; ++i)
         if (!h->tdnn_loaded[i]) return fail(XVEC_ERR_STATE, "time_context_layers.%d weights not loaded", i);
+    for (int i = 0; i < XVEC_NUM_TDNN; ++i)
+        if (!h->folded[i]) return fail(XVEC_ERR_STATE, "internal: time_context_layers.%d not folded", i);
     if (mode == XVEC_MODE_POOLED) return XVEC_OK;
     if (!h->aff_loaded[0]) return fail(XVEC_ERR_STATE, "segment_layer6 weights not loaded");
     if ((mode == XVEC_MODE_XVEC7 || mode == XVEC_MODE_LOGITS) && !h->aff_loaded[1])
@@ -305,8 +341,9 @@ int check_loaded(const xvec_handle* h, int mode) {
     return XVEC_OK;
 }
 
-// merge the pooling partials layer 5 left (in the form of the kernel that ran: xvec_get_dispatch) into pooled[B, 3000]
-int finalize_pool(xvec_handle* h, const float* part, const int* part_cnt, const RowMap& map, float* pooled, hipStream_t s) {
+// merge the pooling partials layer 5 left (in the form of the kernel that wrote them: `d`, from its run_tdnn) into pooled[B, 3000]
+int finalize_pool(xvec_handle* h, const Dispatch& d, const float* part, const int* part_cnt, const RowMap& map, float* pooled,
+                  hipStream_t s) {
     PoolFinalizeArgs f;
     memset(&f, 0, sizeof(f));
     f.part = part;
@@ -317,10 +354,10 @@ int finalize_pool(xvec_handle* h, const float* part, const int* part_cnt, const 
     f.sub_rows = 32;
     f.scale = h->vec[4] + f.n_pad;              // the pooling epilogues leave sums of r = relu(z + bias)
     f.shift = h->vec[4] + 2 * f.n_pad;
-    if (h->last_kernel[4] == XVEC_KERNEL_PP) {     // tdnn_pp16.hip: one partial per (block, utterance, half)
+    if (d.kernel == XVEC_KERNEL_PP) {               // tdnn_pp16.hip: one partial per (block, utterance, half)
         f.cnt = part_cnt;
-        f.units_total = h->pool_units;
-        f.blocks_per_col = h->pool_bpc;
+        f.units_total = d.pool_units;
+        f.blocks_per_col = d.pool_bpc;
     }
     HIP_TRY(launch_pool_finalize(f, s));
     return XVEC_OK;
@@ -370,7 +407,7 @@ int forward_rows(xvec_handle* h, const float* x_rows, int ldx, const int64_t* of
     int ld_in = ldx;
     const int64_t act_plane = p.rows_alloc * (int64_t)nh * 2;        // bytes of one bf16 plane of an activation buffer
     int64_t in_plane = 0;
-    if (b16 && p.total > 0x7fffffff) return fail(XVEC_ERR_ARG, "too many frames for one bf16 batch");
+    if (b16 && p.total > 0x7fffffff) return fail(XVEC_ERR_TOO_LARGE, "too many frames for one bf16 batch; split it");
     if (x3 && !first3) {    // [total, ldx] fp32 -> bf16 hi and lo planes (same row stride in elements)
         StageTimer t(h, T_PACK, s);
         void* x16 = ws + p.x16;
@@ -378,13 +415,14 @@ int forward_rows(xvec_handle* h, const float* x_rows, int ldx, const int64_t* of
         HIP_TRY(launch_pack_rows_split(x_rows, p.total, ldx, ldx, in_plane / 2, x16, s));
         in = x16;
     }
+    Dispatch d5;                                                     // what layer 5 went to: finalize_pool reads its partials
     for (int l = 0; l < XVEC_NUM_TDNN; ++l) {
         map.cum += h->geo[l].ctx_span;
         const int64_t rows_out = p.total - (int64_t)B * map.cum;
         const TdnnVariant v = l == 0 ? v1 : l == 4 ? v5 : vm;
         void* out_buf = l == 4 ? nullptr : bufs[l & 1];
         if ((rc = run_tdnn(h, l, v, in, ld_in, l == 0 ? p.total : 0, out_buf, rows_out, map, l == 4 ? part : nullptr, s,
-                           x3, in_plane, l == 4 ? 0 : act_plane, l == 4 ? part_cnt : nullptr)))
+                           x3, in_plane, l == 4 ? 0 : act_plane, l == 4 ? part_cnt : nullptr, l == 4 ? &d5 : nullptr)))
             return rc;
         in = out_buf;
         ld_in = nh;
@@ -392,7 +430,7 @@ int forward_rows(xvec_handle* h, const float* x_rows, int ldx, const int64_t* of
     }
     {
         StageTimer t(h, T_POOL, s);
-        if ((rc = finalize_pool(h, part, part_cnt, map, pooled, s))) return rc;
+        if ((rc = finalize_pool(h, d5, part, part_cnt, map, pooled, s))) return rc;
     }
     if (mode == XVEC_MODE_POOLED) return XVEC_OK;
     const int xv = h->cfg.x_vector_size, K6 = 2 * XVEC_POOL_CHANNELS;
@@ -452,7 +490,8 @@ int stage_offsets(xvec_handle* h, const int64_t* offs_host, const int32_t* lengt
 int common_checks(xvec_handle* h, const void* x, int B, int mode, int dtype, const void* out, const void* ws) {
     if (!h) return fail(XVEC_ERR_ARG, "null handle");
     if (!x || !out || !ws) return fail(XVEC_ERR_ARG, "null tensor pointer");
-    if (B < 1 || B > kMaxUtts) return fail(XVEC_ERR_ARG, "B must be in [1, %d] (got %d); split larger batches", kMaxUtts, B);
+    if (B < 1) return fail(XVEC_ERR_ARG, "B must be in [1, %d] (got %d)", kMaxUtts, B);
+    if (B > kMaxUtts) return fail(XVEC_ERR_TOO_LARGE, "B must be in [1, %d] (got %d); split larger batches", kMaxUtts, B);
     if (mode != XVEC_MODE_LOGITS && mode != XVEC_MODE_XVEC6 && mode != XVEC_MODE_XVEC7 && mode != XVEC_MODE_POOLED)
         return fail(XVEC_ERR_ARG, "unknown mode %d", mode);
     if (dtype != XVEC_F32 && dtype != XVEC_BF16 && dtype != XVEC_BF16X3) return fail(XVEC_ERR_ARG, "unknown dtype %d", dtype);
@@ -505,6 +544,9 @@ int xvec_create(const xvec_cfg* cfg, xvec_handle** out) {
             hipMalloc(&h->Wp48[i], (size_t)h->geo16[i].n_pad * h->geo16[i].k_pad * 2 * 2) != hipSuccess ||
             hipMalloc(&h->Wr48[i], (size_t)h->geo16[i].n_pad * h->geo16[i].k_pad * 2 * 3) != hipSuccess ||
             hipMalloc(reinterpret_cast<void**>(&h->Wp[i]), (size_t)g.n_pad * g.k_pad * 4) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void**>(&h->Wraw[i]), (size_t)g.cout * g.src_taps * g.src_cin * 4) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void**>(&h->braw[i]), (size_t)g.cout * 4) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void**>(&h->vec16[i]), (size_t)3 * g.n_pad * 4) != hipSuccess ||
             hipMalloc(reinterpret_cast<void**>(&h->vec[i]), (size_t)3 * g.n_pad * 4) != hipSuccess) {
             xvec_destroy(h);
             return fail(XVEC_ERR_HIP, "hipMalloc of packed weights failed");
@@ -545,6 +587,9 @@ void xvec_destroy(xvec_handle* h) {
         if (h->Wp48[i]) (void)hipFree(h->Wp48[i]);
         if (h->Wr48[i]) (void)hipFree(h->Wr48[i]);
         if (h->vec[i]) (void)hipFree(h->vec[i]);
+        if (h->Wraw[i]) (void)hipFree(h->Wraw[i]);
+        if (h->braw[i]) (void)hipFree(h->braw[i]);
+        if (h->vec16[i]) (void)hipFree(h->vec16[i]);
     }
     for (int i = 0; i < 3; ++i) {
         if (h->affW[i]) (void)hipFree(h->affW[i]);
@@ -576,15 +621,20 @@ int xvec_load_tdnn(xvec_handle* h, int layer, const float* weight, const float* 
     HIP_TRY(launch_pack_tdnn(weight, bias, bn_weight, bn_bias, bn_mean, bn_var, eps, g, h->Wp[layer],
                              h->vec[layer], h->vec[layer] + g.n_pad, h->vec[layer] + 2 * g.n_pad,
                              static_cast<hipStream_t>(stream)));
-    HIP_TRY(launch_pack_tdnn_bf16(weight, h->geo16[layer], h->Wp16[layer], static_cast<hipStream_t>(stream)));
-    HIP_TRY(launch_pack_tdnn_rows_bf16(weight, h->geo16[layer], h->Wr16[layer], static_cast<hipStream_t>(stream)));
     HIP_TRY(launch_pack_tdnn_rows_bf16x3(weight, h->geo16[layer], h->Wr48[layer], static_cast<hipStream_t>(stream)));
     {
         TdnnGeom g3 = h->geo16[layer];
         g3.terms = 2;
-        HIP_TRY(launch_pack_tdnn_bf16(weight, g3, h->Wp48[layer], static_cast<hipStream_t>(stream)));
+        HIP_TRY(launch_pack_tdnn_bf16(weight, nullptr, g3, h->Wp48[layer], static_cast<hipStream_t>(stream)));
     }
+    // plain bf16 (BatchNorm deferred into the consumer): this layer's copies depend on its producer's BatchNorm, its
+    // consumer's on this layer's -- whatever the order the layers are loaded in
+    HIP_TRY(hipMemcpyAsync(h->Wraw[layer], weight, (size_t)g.cout * g.src_taps * g.src_cin * 4, hipMemcpyDeviceToDevice,
+                           static_cast<hipStream_t>(stream)));
+    HIP_TRY(hipMemcpyAsync(h->braw[layer], bias, (size_t)g.cout * 4, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
     h->tdnn_loaded[layer] = true;
+    if (int rc = refold(h, layer, static_cast<hipStream_t>(stream))) return rc;
+    if (int rc = refold(h, layer + 1, static_cast<hipStream_t>(stream))) return rc;
     return XVEC_OK;
 }
 
@@ -694,6 +744,8 @@ int xvec_tdnn_layer(xvec_handle* h, int layer, const float* x, int32_t B, int32_
     if (!x || !y || !workspace) return fail(XVEC_ERR_ARG, "null tensor pointer");
     if (dtype != XVEC_F32 && dtype != XVEC_BF16 && dtype != XVEC_BF16X3) return fail(XVEC_ERR_ARG, "unknown dtype %d", dtype);
     if (!h->tdnn_loaded[layer]) return fail(XVEC_ERR_STATE, "time_context_layers.%d weights not loaded", layer);
+    if (dtype == XVEC_BF16 && !h->folded[layer])
+        return fail(XVEC_ERR_STATE, "time_context_layers.%d: plain bf16 folds the BatchNorm of layer %d into it; load that layer too", layer, layer - 1);
     DeviceGuard guard;                 // launches go to the handle's device whatever the caller's current one is
     HIP_TRY(guard.enter(h->cfg.device));
     const TdnnGeom& g = h->geo[layer];
@@ -721,7 +773,11 @@ int xvec_tdnn_layer(xvec_handle* h, int layer, const float* x, int32_t B, int32_
         x_plane = p.rows_alloc * (int64_t)ldx * 2;
         if (!l0_first3) HIP_TRY(launch_pack_rows_split(static_cast<const float*>(x32), p.total, ldx, ldx, x_plane / 2, xin, s));
     } else {
-        HIP_TRY(launch_pack_rows(x, nullptr, B, T, g.src_cin, ldx, xin, rows16, s));
+        // plain bf16, layers 2-5: the kernel reads the producing layer's relu output and carries that layer's BatchNorm in its
+        // weights (refold), so the caller's x -- the reference's layer input, BatchNorm applied -- is taken back through it
+        const float* un = (b16 && layer > 0) ? h->vec[layer - 1] : nullptr;
+        const int npp = layer > 0 ? h->geo[layer - 1].n_pad : 0;
+        HIP_TRY(launch_pack_rows(x, nullptr, B, T, g.src_cin, ldx, xin, rows16, s, un ? un + npp : nullptr, un ? un + 2 * npp : nullptr));
     }
     void* yflat = ws + (layer == 4 || x3 ? p.act5 : p.actB);
     const TdnnVariant v = layer == 0 ? (b16 ? TdnnVariant::kBf16FirstSrc32 : x3 ? TdnnVariant::kBf16FirstToF32 : TdnnVariant::kF32First)
@@ -757,7 +813,9 @@ int xvec_tdnn_layer(xvec_handle* h, int layer, const float* x, int32_t B, int32_
     }
     int rc = run_tdnn(h, layer, v, xin, ldx, p.total, yflat, (int64_t)B * To, map, nullptr, s, x3, x_plane, 0);
     if (rc) return rc;
-    HIP_TRY(launch_unpack_rows(yflat, b16, g.n_pad, B, To, To, g.cout, y, s));
+    // (plain bf16 stored relu(z + bias'): this layer's BatchNorm is applied here, in fp32, as its consumer's weights would)
+    HIP_TRY(launch_unpack_rows(yflat, b16, g.n_pad, B, To, To, g.cout, y, s, b16 ? h->vec[layer] + g.n_pad : nullptr,
+                               b16 ? h->vec[layer] + 2 * g.n_pad : nullptr));
     return XVEC_OK;
 }
 
@@ -768,6 +826,8 @@ int xvec_tdnn_pool_layer(xvec_handle* h, const float* x, int32_t B, int32_t T, i
     if (!x || !out || !workspace) return fail(XVEC_ERR_ARG, "null tensor pointer");
     if (dtype != XVEC_F32 && dtype != XVEC_BF16 && dtype != XVEC_BF16X3) return fail(XVEC_ERR_ARG, "unknown dtype %d", dtype);
     if (!h->tdnn_loaded[layer]) return fail(XVEC_ERR_STATE, "time_context_layers.%d weights not loaded", layer);
+    if (dtype == XVEC_BF16 && !h->folded[layer])
+        return fail(XVEC_ERR_STATE, "time_context_layers.%d: plain bf16 folds the BatchNorm of layer %d into it; load that layer too", layer, layer - 1);
     DeviceGuard guard;
     HIP_TRY(guard.enter(h->cfg.device));
     const TdnnGeom& g = h->geo[layer];
@@ -788,7 +848,9 @@ int xvec_tdnn_pool_layer(xvec_handle* h, const float* x, int32_t B, int32_t T, i
         x_plane = p.rows_alloc * (int64_t)ldx * 2;
         HIP_TRY(launch_pack_rows_split(static_cast<const float*>(x32), p.total, ldx, ldx, x_plane / 2, xin, s));
     } else {
-        HIP_TRY(launch_pack_rows(x, nullptr, B, T, g.src_cin, ldx, xin, in16, s));
+        const float* un = dtype == XVEC_BF16 ? h->vec[layer - 1] : nullptr;     // plain bf16: see xvec_tdnn_layer
+        const int npp = h->geo[layer - 1].n_pad;
+        HIP_TRY(launch_pack_rows(x, nullptr, B, T, g.src_cin, ldx, xin, in16, s, un ? un + npp : nullptr, un ? un + 2 * npp : nullptr));
     }
     RowMap map;
     map.offsets = nullptr;
@@ -797,10 +859,11 @@ int xvec_tdnn_pool_layer(xvec_handle* h, const float* x, int32_t B, int32_t T, i
     map.cum = g.ctx_span;
     float* part = reinterpret_cast<float*>(ws + p.part);
     int* part_cnt = reinterpret_cast<int*>(ws + p.part_cnt);
+    Dispatch d5;
     int rc = run_tdnn(h, layer, in16 ? TdnnVariant::kBf16Pool : TdnnVariant::kF32Pool, xin, ldx, 0, nullptr,
-                      (int64_t)B * (T - g.ctx_span), map, part, s, x3, x_plane, 0, part_cnt);
+                      (int64_t)B * (T - g.ctx_span), map, part, s, x3, x_plane, 0, part_cnt, &d5);
     if (rc) return rc;
-    return finalize_pool(h, part, part_cnt, map, out, s);
+    return finalize_pool(h, d5, part, part_cnt, map, out, s);
 }
 
 int xvec_stat_pool(const float* x, const int32_t* lengths_dev, int32_t B, int32_t T, int32_t C, float* out,

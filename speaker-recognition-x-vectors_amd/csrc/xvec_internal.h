@@ -137,7 +137,11 @@ hipError_t launch_tdnn_first(const TdnnArgs& a, int num_cu, hipStream_t s);
 bool tdnn_first3_applicable(const TdnnArgs& a);
 hipError_t launch_tdnn_first3(const TdnnArgs& a, int num_cu, hipStream_t s);
 // K-tile major bf16 copy of the packed weights for it
-hipError_t launch_pack_tdnn_rows_bf16(const float* W, const TdnnGeom& geo, void* Wr16, hipStream_t s);
+// (in_scale: nullptr, or the producing layer's folded BatchNorm scale per input channel -- plain bf16 defers BatchNorm, pack.hip)
+hipError_t launch_pack_tdnn_rows_bf16(const float* W, const float* in_scale, const TdnnGeom& geo, void* Wr16, hipStream_t s);
+// plain bf16: bias' = bias + W . shift_prev | scale' = 1 | shift' = 0 (3 x n_pad floats), see pack.hip
+hipError_t launch_fold_bias(const float* W, const float* bias, const float* in_shift, const TdnnGeom& geo, float* vec16,
+                            hipStream_t s);
 // ... and for its bf16x3 form (a.terms == 2): [n_pad/256][3 * k_pad/64][256][64], per K-tile W_hi | W_lo | W_hi
 hipError_t launch_pack_tdnn_rows_bf16x3(const float* W, const TdnnGeom& geo, void* Wr48, hipStream_t s);
 
@@ -174,17 +178,20 @@ hipError_t launch_pack_tdnn(const float* W, const float* bias, const float* g, c
                             float* Wp, float* bias_p, float* scale_p, float* shift_p, hipStream_t s);
 // bf16 fragment-major packing: block (column tile ct of 32 channels, k-step ks of 16) = 64 lanes x 8 bf16,
 // lane (r,h) element j = W[32*ct + r][16*ks + 8*h + j]
-hipError_t launch_pack_tdnn_bf16(const float* W, const TdnnGeom& geo, void* Wf16, hipStream_t s);
+hipError_t launch_pack_tdnn_bf16(const float* W, const float* in_scale, const TdnnGeom& geo, void* Wf16, hipStream_t s);
 // x[B,T,C] (+lengths) -> packed rows [sum len, c_pad] (fp32 or bf16); offsets on device
+// un_scale / un_shift: nullptr, or a folded BatchNorm to invert on the way in (per-layer entries in plain bf16, pack.hip)
 hipError_t launch_pack_rows(const float* x, const int64_t* offsets, int B, int T, int C, int c_pad,
-                            void* out, bool out_bf16, hipStream_t s);
+                            void* out, bool out_bf16, hipStream_t s, const float* un_scale = nullptr,
+                            const float* un_shift = nullptr);
 // x[rows][C] fp32 -> bf16 planes hi | lo, each [.][c_pad], lo plane plane_elems elements after hi (bf16x3)
 hipError_t launch_pack_rows_split(const float* x, int64_t rows, int C, int c_pad, int64_t plane_elems, void* out,
                                   hipStream_t s);
 // flat [rows, ld] (fp32 or bf16) -> compact fp32 y[B, T_out, C]
 hipError_t launch_unpack_rows_split(const void* flat, int64_t plane_elems, int ld, int B, int T_in, int T_out, int C,
                                     float* y, hipStream_t s);
+// scale / shift: nullptr, or a folded BatchNorm applied on the way out
 hipError_t launch_unpack_rows(const void* flat, bool in_bf16, int ld, int B, int T_in, int T_out, int C,
-                              float* y, hipStream_t s);
+                              float* y, hipStream_t s, const float* scale = nullptr, const float* shift = nullptr);
 
 }  // namespace xvec

@@ -96,8 +96,12 @@ def extract_sharded(extract_fn: Callable[[torch.Tensor], torch.Tensor], make_bat
 
     A rank whose block is empty (n_total < world * ceil(n_total / world)) extracts nothing: it joins the
     all-gather with a [0, D] shard, D = `embed_dim` or, when that is not given, learnt from its peers by one
-    scalar all-reduce (every rank takes part in it, and only when the last rank's block is empty)."""
+    scalar all-reduce (every rank takes part in it, and only when the last rank's block is empty).  Such a rank has no
+    tensor to take its device from: pass `device`, or -- with the "nccl" backend -- have torch.cuda.set_device(local_rank)
+    called before (bench.py does), since the fallback is the process's CURRENT device."""
     import torch.distributed as dist
+    if n_total < 1:                        # on EVERY rank, before any collective: nobody is left waiting in one
+        raise ValueError("extract_sharded: nothing to extract (n_total < 1)")
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     lo, hi = shard_bounds(n_total, rank, world)
@@ -118,8 +122,6 @@ def extract_sharded(extract_fn: Callable[[torch.Tensor], torch.Tensor], make_bat
             D = int(t.item())
         if local is None:
             local = torch.zeros((0, D), dtype=torch.float32, device=device)
-    if local is None:
-        raise ValueError("extract_sharded: nothing to extract (n_total < 1)")
     return gather_embeddings(local, n_total, group, force=force_collective)
 
 

@@ -26,7 +26,7 @@ if _override:
     print(f"[xvector_amd] XVEC_LIB override: loading {_override}", file=sys.stderr)
 LIB_PATH = _override or os.path.join(_HERE, "libxvec_hip.so")
 
-OK, ERR_ARG, ERR_HIP, ERR_STATE, ERR_WORKSPACE = 0, 1, 2, 3, 4
+OK, ERR_ARG, ERR_HIP, ERR_STATE, ERR_WORKSPACE, ERR_TOO_LARGE = 0, 1, 2, 3, 4, 5
 F32, BF16, BF16X3 = 0, 1, 2
 MODE_LOGITS, MODE_POOLED, MODE_XVEC6, MODE_XVEC7 = 0, 5, 6, 7
 SEG6, SEG7, OUTPUT = 6, 7, 8

@@ -293,22 +293,30 @@ class XVectorModel(nn.Module):
         return (0x3FFFFFFF // (hidden_pad * 2)) - 1024            # rows_alloc = frames rounded up to 128, + 264
 
     @staticmethod
-    def _call_ranges(B: int, T: int, max_frames: Optional[int], max_utts: int):
+    def _call_ranges(B: int, T: int, max_frames: Optional[int], max_utts: int, pool_pad: int = 1536, partial_limit: bool = True):
         """[lo, hi) utterance ranges of a [B, T, .] batch such that no range exceeds `max_frames` padded frames or
-        `max_utts` utterances (a service handing over more than one call can hold gets several calls, not an error)."""
+        `max_utts` utterances (a service handing over more than one call can hold gets several calls, not an error).
+        `partial_limit`: the pooling partials of the 128x128 kernels (one slot per 32 frames and utterance, 3 planes of
+        `pool_pad` = layer 5's padded width floats) are addressed with 32 bits and must stay below 2 GiB per call; the
+        large-batch kernel's partials have no such limit (whatever this estimate misses, the library answers with
+        XVEC_ERR_TOO_LARGE and _run halves the batch)."""
         per = max_utts if max_frames is None else min(max_utts, max_frames // T)
         if per < 1:
             raise ValueError(f"one utterance of {T} frames exceeds the {max_frames} frames a call can hold in this precision")
-        # pooling partials of one call stay below 2 GiB: (frames/32 + utterances + 1) slots x 3 planes x 1536 x 4 bytes
-        # (a single utterance beyond that -- 3.7 M frames, ten hours -- is refused by the library)
-        per = max(1, min(per, int((0x7FFFFFFF // (3 * 1536 * 4) - 2) / (T / 32.0 + 1.0))))
+        if partial_limit:
+            # (a single utterance beyond that -- 3.7 M frames, ten hours -- is refused by the library)
+            per = max(1, min(per, int((0x7FFFFFFF // (3 * pool_pad * 4) - 2) / (T / 32.0 + 1.0))))
         return [(lo, min(lo + per, B)) for lo in range(0, B, per)]
 
     def _run(self, x: torch.Tensor, mode: int, lengths=None, workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
         x = self._prep_input(x, "XVectorModel")
         B, T, Cin = x.shape
         if workspace is None:
-            ranges = self._call_ranges(B, T, self._max_frames_per_call(), self.MAX_UTTS_PER_CALL)
+            # layer 5 of a bf16 / bf16x3 batch this large goes to the large-batch kernel, whose partials have no 2 GiB limit
+            # (xvec_api.hip, pp_blocks_per_col: 256-channel columns and >= 1.8 units of 64 frames per CU; 1536 = 6 columns)
+            big = self.precision != "fp32" and B * (T - TOTAL_CONTEXT) >= 64 * 1024
+            ranges = self._call_ranges(B, T, self._max_frames_per_call(), self.MAX_UTTS_PER_CALL,
+                                       pool_pad=-(-POOL_CHANNELS // 128) * 128, partial_limit=not big)
             if len(ranges) > 1:
                 if lengths is not None and torch.is_tensor(lengths):
                     lengths = lengths.detach().cpu().tolist()
@@ -334,9 +342,9 @@ class XVectorModel(nn.Module):
         with torch.cuda.device(x.device):
             rc = _hip.lib.xvec_forward(eng.h, x.data_ptr(), arr, B, T, mode, _DTYPES[self.precision],
                                        out.data_ptr(), ws, ws_bytes, _stream_ptr(x.device))
-        if rc == _hip.ERR_ARG and B > 1 and workspace is None and "split" in _hip.last_error():
+        if rc == _hip.ERR_TOO_LARGE and B > 1 and workspace is None:
             # one of the library's per-call size limits (32-bit row offsets, pooling partials < 2 GiB, 30-bit bf16x3
-            # planes: include/xvec_hip.h) that _call_ranges did not foresee: two calls of half the batch each
+            # planes: include/xvec_hip.h, XVEC_ERR_TOO_LARGE) that _call_ranges did not foresee: two calls of half the batch each
             half = B // 2
             return torch.cat([self._run(x[:half], mode, None if lens is None else lens[:half]),
                               self._run(x[half:], mode, None if lens is None else lens[half:])], 0)

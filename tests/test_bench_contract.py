@@ -99,3 +99,47 @@ def test_job_workload_on_the_gpu():
                    "--force-collective", "--cpu-budget", "0"])
     assert d["scaling"] == "strong" and d["value"] > 0 and d["n_gpus"] == 1
     assert "configs[3]" in d["config"]["workload"] and "2000 utterances" in d["config"]["workload"]
+
+
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def test_torchrun_form_sets_the_ipc_variable_in_every_rank():
+    """The contract's OTHER launch form -- `python -m torch.distributed.run ... bench.py --gpus 2` -- with
+    HSA_ENABLE_IPC_MODE_LEGACY absent from the parent's environment: every rank must still see it as "0" (RCCL across
+    processes fails at communicator creation without it on this driver; VERDICT r03: only self_launch() set it)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "HSA_ENABLE_IPC_MODE_LEGACY")}
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "2",
+           "--batch", "4", "--report-env"]
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    env_lines = [l for l in out.stderr.splitlines() if l.startswith("ENV ")]
+    assert len(env_lines) == 1, out.stderr[-2000:]
+    assert json.loads(env_lines[0][4:]) == {"HSA_ENABLE_IPC_MODE_LEGACY": ["0", "0"]}
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 2
+
+
+@pytest.mark.parametrize("form", ["self", "torchrun"])
+def test_a_rank_that_dies_before_the_first_barrier_ends_the_job(form):
+    """One rank raises before the first barrier: the job exits non-zero well inside the process-group timeout instead
+    of leaving its peer in the barrier for torch's default 10 minutes, and no JSON line is printed."""
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    tail = ["--gpus", "2", "--dry-run", "--steps", "2", "--batch", "4", "--fail-rank", "1", "--dist-timeout", "20"]
+    if form == "self":
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + tail
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py")] + tail
+    t0 = time.time()
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode != 0, out.stdout[-500:]
+    assert time.time() - t0 < 120, "the surviving rank was not released by the timeout / the launcher"
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert "simulated rank failure" in out.stderr

@@ -258,8 +258,44 @@ def test_call_ranges_split_a_batch_that_one_call_cannot_hold():
     assert R(70000, 20, None, 65535) == [(0, 65535), (65535, 70000)]
     assert R(7, 400, 1000, 65535) == [(0, 2), (2, 4), (4, 6), (6, 7)]
     assert R(20000, 300, None, 65535) == [(0, 11229), (11229, 20000)]     # pooling partials < 2 GiB per call
+    assert R(20000, 300, None, 65535, pool_pad=1536, partial_limit=False) == [(0, 20000)]   # large-batch partials: no such limit
+    assert R(20000, 300, None, 65535, pool_pad=3072) == [(0, 5614), (5614, 11228), (11228, 16842), (16842, 20000)]   # from the model's width, not a literal
     with pytest.raises(ValueError, match="exceeds"):
         R(2, 2000, 1000, 65535)
     m = xa.XVectorModel(precision="bf16x3")
     assert 1_000_000 < m._max_frames_per_call() < (1 << 20)
     assert xa.XVectorModel(precision="bf16")._max_frames_per_call() is None
+
+
+def test_traffic_json_is_tied_to_the_built_library():
+    """profiles/traffic.json (the PMC bytes bench.py quotes as roofline.traffic; counters cannot be read inside the bench
+    process) must describe THIS build: every kernel key bench.py can look up, and every key in the file, is a kernel of the
+    freshly built libxvec_hip.so (demangled symbols), and the file's `source` names the newest committed profile round.
+    Renaming or re-templating a kernel without re-running profiles/run_round.sh turns this red."""
+    import glob
+    import json
+    import re
+    import shutil
+    import subprocess
+    import bench
+    if shutil.which("nm") is None:
+        pytest.skip("needs binutils nm")
+    lib = os.path.join(ROOT, "speaker-recognition-x-vectors_amd", "libxvec_hip.so")
+    syms = subprocess.run(["nm", "-C", lib], capture_output=True, text=True, check=True).stdout
+    kernels = {m.group(1) for m in re.finditer(r"__device_stub__(\S[^\n]*?)\(", syms)}   # name incl. template arguments
+    full = {re.sub(r"__device_stub__", "", m.group(0)[:-1]) for m in re.finditer(r"\S*__device_stub__[^\n]*?\(", syms)}
+    assert len(kernels) > 30, "could not list the library's kernels"
+    tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    rounds = sorted(int(m.group(1)) for f in glob.glob(os.path.join(ROOT, "profiles", "r*_kernel_stats*.csv"))
+                    for m in [re.match(r"r(\d+)_", os.path.basename(f))] if m)
+    newest = f"r{rounds[-1]:02d}"
+    for dtype in ("fp32", "bf16", "bf16x3"):
+        sec = tj[dtype]
+        assert f"gpurun_out/{newest}" in sec["source"], f"traffic.json[{dtype}] comes from {sec['source']!r}, newest profile set is {newest}"
+        for pp in (True, False):
+            key = bench.traffic_key(dtype, pp)
+            assert any(key in k for k in full), f"bench.py's traffic key {key!r} is not a kernel of the built library"
+        assert bench.traffic_key(dtype, dtype != "fp32") in sec, f"traffic.json[{dtype}] lacks the dominant kernel of the bench batch"
+        for key in sec:
+            if key != "source":
+                assert any(key in k for k in full), f"traffic.json[{dtype}] names {key!r}, which the built library does not contain"

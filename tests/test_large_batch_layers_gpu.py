@@ -81,6 +81,17 @@ def _oracle_layer_uncached(x_cpu, p64, layer, chunk=32):
     return torch.cat(outs)
 
 
+def _pre_bn(y, sd, layer):
+    """The ReLU output behind a layer's eval BatchNorm (tdnn_layer.py:36-39 inverted, fp64).  Plain bf16 stores exactly that
+    (rounded to bf16) and leaves the BatchNorm to the consumer's weights; kernel-against-kernel comparisons at the one-ulp
+    level belong in this domain -- behind the BatchNorm an ulp of r is |scale| * 2^-8 r next to a y = scale * r + shift
+    that may have cancelled to anything."""
+    k = f"time_context_layers.{layer}.norm."
+    sc = (sd[k + "weight"].double() / torch.sqrt(sd[k + "running_var"].double() + 1e-5)).to(y.device)
+    sh = (sd[k + "bias"].double() - sd[k + "running_mean"].double() * sc.cpu()).to(y.device)
+    return (y.double() - sh) / sc
+
+
 def _ulp_report(a, b):
     d = (a.double() - b.double()).abs()
     return float((d / b.double().abs().clamp_min(1e-3)).max()), int((d > 0).sum())
@@ -103,8 +114,9 @@ def test_bf16_every_layer_every_element(gpu_model, sd42, synth, models, B, T):
         old = m_old.time_context_layers[i](h)
         assert m_old.last_dispatch()[i] == "tile128"
         # (measured: 1.1e-3 row-wise for layer 1, 2-4e-4 for the others; a corrupted row is at 2e-2 and more)
-        assert_parity(got, old, 3e-3 if i == 0 else 1e-3, f"bf16 layer {i} B={B} T={T} large-batch vs 128x128 kernel",
-                      elem_tol=1e-2)
+        # compared as the kernels store them: the ReLU outputs, before this layer's BatchNorm (_pre_bn)
+        assert_parity(_pre_bn(got, sd42, i), _pre_bn(old, sd42, i), 3e-3 if i == 0 else 1e-3,
+                      f"bf16 layer {i} B={B} T={T} large-batch vs 128x128 kernel", elem_tol=1e-2)
         h = gpu_model.time_context_layers[i](h)       # next layer's input: the fp32 path's output
 
 
@@ -123,7 +135,10 @@ def test_bf16_fused_pooling_layer(gpu_model, sd42, synth, models, B, T):
     assert torch.equal(got, m_pp.pooled_last_layer(h))
     old = m_old.pooled_last_layer(h)
     assert m_old.last_dispatch()[4] == "tile128"
-    assert_parity(got, old, 2e-5, f"pooled B={B} T={T}: large-batch vs 128x128 kernel", elem_tol=1e-4)
+    # (the large-batch kernel sums bf16-rounded deviations on the matrix pipe -- tdnn_pp16.hip, SegMx: 2^-9 of random error
+    #  per frame and value, ~1e-4 of a statistic over 286 frames -- the 128x128 kernel fp32 ones; a single corrupted frame
+    #  moves a mean by 1/286 = 3.5e-3 of a value)
+    assert_parity(got, old, 1e-3, f"pooled B={B} T={T}: large-batch vs 128x128 kernel", elem_tol=5e-3)
     idx = sorted({0, 1, B // 3, B // 2, B - 2, B - 1})
     ref = torch.cat([oracle.stat_pool(_oracle_layer(h[j:j + 1].cpu(), p64, 4).double()) for j in idx])
     assert_parity(got[idx], ref, 1e-2, f"pooled B={B} T={T} vs oracle")

@@ -298,16 +298,18 @@ def test_extreme_shapes(sd42, synth, precision, tol):
     assert n_big == 65535 or precision == "bf16x3"
     outb = m.extract_x_vec(big)
     alone = m.extract_x_vec(big[:5])
-    # bf16: the large batch runs the 256-channel mapping (tdnn_pp16.hip: bias in the accumulator's start value,
-    # raw-sum pooling), five utterances run the 128x128 kernel -- same arithmetic type, different rounding
-    # order (measured 3e-5; either is 9e-4 from fp32).  fp32 / bf16x3 have one kernel: bit-level agreement.
-    same = 2e-4 if precision == "bf16" else 1e-5
+    # bf16 / bf16x3: the large batch runs the 256-channel mapping (tdnn_pp16.hip), five utterances the 128x128 kernel --
+    # the same arithmetic type in another summation order; in plain bf16 the large-batch pooling also sums bf16-rounded
+    # deviations on the matrix pipe (~1e-4 of a statistic; either result is 9e-4 from fp32).  fp32 has one kernel.
+    same = 1e-3 if precision == "bf16" else 1e-5
     assert_parity(outb[:5], alone, same, "max batch head")
     assert_parity(outb[-5:], alone, same, "max batch tail")
     # the same utterance at another place in the batch: equal to fp32 rounding, not bit for bit -- the fused pooling
     # sums deviations from a pivot (the first frame of the 32-row group the rows fall in, csrc/tdnn_common.h), which
     # depends on the position; repeat runs of the same batch ARE bit-identical (test_full_size_properties)
-    assert_parity(outb[5:10], outb[n_big - 5:n_big], 1e-5, "same utterances, other batch position")
+    # (plain bf16 on the large-batch kernel: the pooling pivot is per (block, wave) and the deviations are rounded to bf16 --
+    #  tdnn_pp16.hip, SegMx -- so the position shows at ~1e-4, well inside the arithmetic's 1e-2 bar; documented in INTEGRATION.md)
+    assert_parity(outb[5:10], outb[n_big - 5:n_big], 1e-5 if precision != "bf16" else same, "same utterances, other batch position")
     # one utterance more than a library call takes: the host module makes two calls of it (round 1 raised here);
     # the C entry point itself still refuses
     over = torch.cat([big, big[:1]], 0) if n_big == 65535 else big
@@ -320,7 +322,7 @@ def test_extreme_shapes(sd42, synth, precision, tol):
     import ctypes as C
     rc = _hip.lib.xvec_forward(eng.h, C.c_void_p(over.data_ptr()), None, 65536, 16, 6, 0, C.c_void_p(outo.data_ptr()),
                                C.c_void_p(eng.workspace.data_ptr()), C.c_size_t(eng.workspace.numel()), None)
-    assert rc == 1 and "65535" in _hip.last_error()          # XVEC_ERR_ARG: B must be in [1, 65535]
+    assert rc == _hip.ERR_TOO_LARGE and "65535" in _hip.last_error()          # B must be in [1, 65535]: split the batch
 
 
 @pytest.mark.parametrize("case,precision", [(c, "fp32") for c in range(12)] + [(c, "bf16") for c in (0, 3, 5, 8, 11)]

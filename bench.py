@@ -448,12 +448,46 @@ def main():
             "ragged_workload": f"configs[2]: batch={B} utterances of 200-1000 frames (numpy default_rng(1234)), zero-padded "
                                f"to {Tr} with a lengths mask, fp32"})
 
+    def next_row_legs():
+        """The rows either side of the path, short timed loops, never `value`: waveform -> MFCC ->
+        path in fp32 and bf16, the MFCC kernel alone, and the PLDA score matrix of a VoxCeleb1-test-sized set."""
+        K4 = min(K, 20)
+        wv = 0.1 * torch.randn((B, 48000), generator=gen, device=dev, dtype=torch.float32)     # 3 s at 16 kHz (dataset.py:124-135)
+        fe2 = xa.MfccFrontEnd(device=dev)
+
+        def timed(fn, n, pre=0.15):
+            preroll(fn, min(args.preroll, pre))
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize(dev)
+            t = time.perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize(dev)
+            return (time.perf_counter() - t) / n
+
+        secondary["wave_utt_per_s"] = round(B / timed(lambda: model.extract_x_vec(fe2(wv)), K4), 1)
+        m16w = xa.XVectorModel(precision="bf16")
+        m16w.load_state_dict(sd)
+        m16w = m16w.to(dev).eval()
+        secondary["wave_bf16_utt_per_s"] = round(B / timed(lambda: m16w.extract_x_vec(fe2(wv)), K4), 1)
+        del m16w
+        secondary["mfcc_us_per_batch"] = round(timed(lambda: fe2(wv), 50, 0.05) * 1e6, 2)
+        secondary["mfcc_algorithmic_gb_per_s"] = round(B * (48000 * 4 + 299 * 24 * 4) / (secondary["mfcc_us_per_batch"] * 1e-6) / 1e9, 1)
+        n_sc = 4874                                                    # VoxCeleb1 test set (plda_score_stat.py:19-20: every x-vector against every other)
+        mean, F, Sigma = xa.synth.make_plda(512, 200, seed=21)
+        scorer = xa.scoring.PldaScorer(mean, F, Sigma, device=dev)
+        xs = torch.randn((n_sc, 512), generator=gen, device=dev, dtype=torch.float32).double() + torch.from_numpy(mean).to(dev)
+        secondary["plda_score_ms_n4874"] = round(timed(lambda: scorer.score(xs), 10, 0.05) * 1e3, 4)
+        secondary["plda_gemm_tflops_f64"] = round(2.0 * n_sc * n_sc * 512 / (secondary["plda_score_ms_n4874"] * 1e-3) / 1e12, 1)
+
     if (world == 1 and not args.force_collective and not args.no_secondary and args.workload == "fixed"
             and args.dtype == "fp32"):
-        try:
-            secondary_legs()
-        except Exception as e:      # noqa: BLE001
-            print(f"bench.py: secondary legs skipped ({type(e).__name__}: {e})", file=sys.stderr, flush=True)
+        for leg in (secondary_legs, next_row_legs):
+            try:
+                leg()
+            except Exception as e:      # noqa: BLE001
+                print(f"bench.py: {leg.__name__} skipped ({type(e).__name__}: {e})", file=sys.stderr, flush=True)
 
     if rank == 0:
         act_bytes_scale = 0.5 if args.dtype == "bf16" else 1.0     # bf16x3 moves two bf16 planes = fp32 bytes

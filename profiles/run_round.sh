@@ -2,7 +2,7 @@
 # Round profile set (run on the GPU box via gpurun):  bash profiles/run_round.sh <tag>
 #   kernel-trace stats of the default bench line (fp32 + its secondary legs), of --dtype bf16 and of --dtype bf16x3,
 #   FETCH_SIZE / WRITE_SIZE passes for both, utilisation counters for both.  Output: gpurun_out/<tag>/
-tag=${1:-r03}
+tag=${1:-r04}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/$tag
@@ -35,5 +35,16 @@ for dt in fp32 bf16 bf16x3; do
   done
   python3 profiles/summarize_pmc.py $out/pmc_$dt > $out/pmc_summary_$dt.txt 2>&1
 done
-python3 profiles/make_traffic.py fp32=$out/pmc_fp32 bf16=$out/pmc_bf16 bf16x3=$out/pmc_bf16x3 > $out/traffic.json
+# next rows N3 / N4: the MFCC kernel and the fp64 score GEMM (traffic + the MFCC kernel's LDS / issue counters)
+mkdir -p $out/pmc_next
+i=0
+for grp in "FETCH_SIZE" "WRITE_SIZE" \
+           "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU GRBM_GUI_ACTIVE" \
+           "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
+  i=$((i+1))
+  rocprofv3 --pmc $grp --output-format csv -d $out/pmc_next/p$i -o p$i -- python3 profiles/diag/next_rows_pmc.py > $out/pmc_next/p$i.log 2>&1
+  echo "pmc next rows pass $i exit $?"
+done
+python3 profiles/summarize_pmc.py $out/pmc_next > $out/pmc_summary_next.txt 2>&1
+python3 profiles/make_traffic.py fp32=$out/pmc_fp32 bf16=$out/pmc_bf16 bf16x3=$out/pmc_bf16x3 next_rows=$out/pmc_next > $out/traffic.json
 find $out -name "*kernel_stats.csv" | head

@@ -13,9 +13,9 @@ for path in sorted(glob.glob(os.path.join(root, "**", "*counter_collection.csv")
     with open(path) as f:
         for row in csv.DictReader(f):
             k = row["Kernel_Name"]
-            if "xvec::" not in k:
+            if "xvec::" not in k and "mfcc" not in k:       # (the MFCC kernels live in an anonymous namespace)
                 continue
-            k = k.replace("void xvec::", "").replace("(xvec::TdnnArgs)", "").split("(")[0]
+            k = k.replace("void xvec::", "").replace("void ", "").replace("(xvec::TdnnArgs)", "").replace("(anonymous namespace)::", "").split("(")[0]
             agg[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
 # HBM traffic per launch, corrected as MI355X_MICROARCH.md (HBM section) prescribes for gfx950:
 # FETCH_SIZE (KiB) under-reports wide coalesced reads by exactly 2x, WRITE_SIZE (KiB) is exact.

@@ -10,11 +10,10 @@
 // one 32-frame group at a time.  The group's input -- 32 windows of 120 consecutive floats, 96 B apart -- is
 // fetched by the 256 threads together (one 16-wide k-step of one frame each, 64 contiguous bytes), rounded to
 // bf16 and parked in an 8 KiB LDS tile (two tiles: the next group is fetched into registers while this one is
-// multiplied; one barrier per group).  Accumulator PAIRS share their lanes' channels: lane r of the even
-// accumulator is channel 2r of a 64-channel block, lane r of the odd one channel 2r+1 (which column of W a lane
-// multiplies is only a matter of which fragment bytes it loaded), so one v_cvt_pk_bf16_f32 joins the two values
-// into the dword that belongs at column 2r and a store instruction writes two whole 128-byte row segments --
-// the shape the memory system takes at full rate.  (The transposed product with 16-byte stores per lane, which
+// multiplied; one barrier per group).  A lane's four accumulators hold FOUR ADJACENT channels (lane r of accumulator cg is
+// channel 4r + cg of the wave's 128: which column of W a lane multiplies is only a matter of which fragment bytes it
+// loaded), so two v_cvt_pk_bf16_f32 make the 8 bytes that belong at column 4r and a store instruction writes two whole
+// 256-byte row segments: 16 store instructions per group and wave (round 3: dwords at column 2r, 32 instructions).  (The transposed product with 16-byte stores per lane, which
 // touches 32 rows x 32 B per instruction, measured the same here; what did cost time was every wave waiting
 // for its stores to be acknowledged at each group's barrier, see XF_LDS_BARRIER.)  No per-tile descriptors,
 // no tile switch; the utterance bookkeeping (input row = output row + 4 x utterance index) is two scalar
@@ -122,14 +121,16 @@ __global__ __launch_bounds__(256, 2) void tdnn_first_kernel(const TdnnArgs a) {
         cst[1024 + i] = a.shift[i];
     }
     // this wave's weights: channels [128*wave, +128).  Accumulator cg, lane r <-> channel
-    //   ch = 128*wave + 64*(cg>>1) + 2*r + (cg&1);
-    // the fragment-major packing (pack.hip) keeps W[32*ct + l][16*ks + 8*h ..+7] at ((ct*8 + ks)*64 + l + 32*h)*16 B
+    //   ch = 128*wave + 4*r + cg:
+    // a lane's four accumulators hold FOUR adjacent channels of a frame, which the epilogue writes as one 8-byte piece (which
+    // column of W a lane multiplies is only a matter of which fragment bytes it loaded).  The fragment-major packing (pack.hip)
+    // keeps W[32*ct + l][16*ks + 8*h ..+7] at ((ct*8 + ks)*64 + l + 32*h)*16 B
     u32x4 wf[4][8];
     {
         const __amdgpu_buffer_rsrc_t wr = make_rsrc(a.Wf);
 #pragma unroll
         for (int cg = 0; cg < 4; ++cg) {
-            const int ch = 128 * wave + 64 * (cg >> 1) + 2 * r + (cg & 1);
+            const int ch = 128 * wave + 4 * r + cg;
             const int voff = ((ch >> 5) * 8 * 64 + (ch & 31) + 32 * h) * 16;
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks)
@@ -155,12 +156,10 @@ __global__ __launch_bounds__(256, 2) void tdnn_first_kernel(const TdnnArgs a) {
     __syncthreads();                               // constants + tile 0 visible
 
     const char* frag = smem + r * kRowB + 16 * h;  // A operand of lane (r, h): frame r, k = 16*ks + 8*h ..+7
-    // epilogue constants of this lane's four channels (pair p: 128*wave + 64*p + 2r, +1)
-    float2 bi[2];
-#pragma unroll
-    for (int p = 0; p < 2; ++p) bi[p] = *reinterpret_cast<const float2*>(cst + 128 * wave + 64 * p + 2 * r);
-    // accumulator element e of lane (r, h): frame (e&3) + 8*(e>>2) + 4*h; the lane's dword sits at column 2r
-    const int y_voff = (4 * h * a.ldy + 128 * wave + 2 * r) * 2;
+    // bias of this lane's four channels (128*wave + 4r ..+3)
+    const float4 bi = *reinterpret_cast<const float4*>(cst + 128 * wave + 4 * r);
+    // accumulator element e of lane (r, h): frame (e&3) + 8*(e>>2) + 4*h; the lane's 8 bytes sit at column 4r
+    const int y_voff = (4 * h * a.ldy + 128 * wave + 4 * r) * 2;
     // __syncthreads() is `s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier`: it would hold every wave until its 32 stores
     // of the group are acknowledged by memory.  Only the LDS traffic has to be ordered here.
 #define XF_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -183,16 +182,17 @@ __global__ __launch_bounds__(256, 2) void tdnn_first_kernel(const TdnnArgs a) {
         /* bias + ReLU (tdnn_layer.py:30-31; the BatchNorm behind it, :36-39, is deferred into layer 2's weights: */ \
         /* xvec_api.hip, refold); rows of the group at g*32 (the row buffer is padded past the last valid frame) */ \
         const __amdgpu_buffer_rsrc_t yr = make_rsrc(static_cast<char*>(a.Y) + (g_) * 32 * (int64_t)a.ldy * 2);    \
-        _Pragma("unroll") for (int p = 0; p < 2; ++p)                                                             \
-            _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                                      \
-                const float v0 = acc[2 * p][e] + bi[p].x, v1 = acc[2 * p + 1][e] + bi[p].y;                        \
-                unsigned pk = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{v0, v1}, bf16x2));       \
-                asm("v_pk_max_i16 %0, %1, 0" : "=v"(pk) : "v"(pk));   /* ReLU of the packed pair (tdnn_pp16.hip, relu_pk_bf16) */ \
-                __builtin_amdgcn_raw_buffer_store_b32(pk, yr, y_voff, (((e & 3) + 8 * (e >> 2)) * a.ldy + 64 * p) * 2, 0); \
-            }                                                                                                     \
+        _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                                          \
+            u32x2v pk = {__builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{acc[0][e] + bi.x, acc[1][e] + bi.y}, bf16x2)), \
+                         __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{acc[2][e] + bi.z, acc[3][e] + bi.w}, bf16x2))}; \
+            asm("v_pk_max_i16 %0, %1, 0" : "=v"(pk[0]) : "v"(pk[0]));   /* ReLU of the packed pair (tdnn_pp16.hip, relu_pk_bf16) */ \
+            asm("v_pk_max_i16 %0, %1, 0" : "=v"(pk[1]) : "v"(pk[1]));                                             \
+            __builtin_amdgcn_raw_buffer_store_b64(pk, yr, y_voff, ((e & 3) + 8 * (e >> 2)) * a.ldy * 2, 0);      \
+        }                                                                                                         \
         XF_LDS_BARRIER() /* the other tile is written, this one read by every wave */                            \
     }
     typedef float f32x2v __attribute__((ext_vector_type(2)));
+    typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
     for (int64_t g = g_begin; g < g_end; g += 2) {
         XF_GROUP(g, 0, sb, sa)
         if (g + 1 < g_end) XF_GROUP(g + 1, 1, sa, sb)

@@ -736,9 +736,12 @@ __device__ __forceinline__ unsigned pk_min_u16(unsigned x, unsigned y) {
     asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
     return r;
 }
+// (volatile asm: as a plain conversion hipcc hoists all sixteen of a group above the first MFMA pair -- sixteen more live
+//  registers in an epilogue that has two to spare)
 __device__ __forceinline__ unsigned cvt_pk(float x, float y) {
-    typedef float f32x2v __attribute__((ext_vector_type(2)));
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{x, y}, bf16x2));
+    unsigned r;
+    asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+    return r;
 }
 
 // The pooling MFMAs are inline asm with the accumulator TIED, like the K loop's (PP_MF): with the builtin hipcc gave every
@@ -751,8 +754,6 @@ __device__ __forceinline__ unsigned cvt_pk(float x, float y) {
 //   * MFMA write -> vector read (4 passes: 7 wait states): PMX_SETTLE() closes every group, PP_MFMA_SETTLE() every fold;
 //   * the same accumulator in two MFMAs of a group (a01 / a23): a dependent chain, interlocked by the hardware like the
 //     K loop's.
-// ONE code path per group: a whole group runs the masked form with an all-ones mask (16 more v_and per group and wave, but
-// no second copy of the group's code and no merge of two register assignments of the accumulators).
 #define PMX_MFS(pk_, ONES_, A_, G_)                                                                            \
     if constexpr (PP_KNOCK_MXMF) asm volatile("" : "+v"(A_), "+v"(G_) : "v"(ONES_), "v"(pk_)); else                 \
     asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %2, %3, %0\n\tv_mfma_f32_16x16x32_bf16 %1, %3, %3, %1"     \
@@ -826,21 +827,24 @@ __device__ __forceinline__ int rel_row(int64_t row, int64_t base) {
 // unsigned 16-bit patterns the larger of a bf16 x and a bf16 m <= 0 is their MINIMUM (a positive x is below 0x8000 <= m; of two
 // negative values the smaller pattern is the smaller magnitude) -- one v_pk_min_u16 per pair instead of two v_max_f32.  The same
 // instruction masks: where a frame lies outside the segment the operand's half is 0x0000, and min(x, 0) = +0 whatever x holds.
-#define PMX_PACKM(pk_, cb_, v0_, v1_)                                                                          \
+#define PMX_PACKM(pk_, cb_, v0_, v1_, MASKED_)                                                                 \
     u32x4 pk_ = ones_e;                                                                                        \
     if constexpr (!PP_KNOCK_MXPK) {                                                                            \
-        const u32x4 m_ = mk & ncp[cb_];                                                                        \
+        const u32x4 m_ = MASKED_ ? mk & ncp[cb_] : u32x4{ncp[cb_], ncp[cb_], ncp[cb_], ncp[cb_]};             \
         pk_ = u32x4{pk_min_u16(cvt_pk(v0_[0], v0_[1]), m_[0]), pk_min_u16(cvt_pk(v0_[2], v0_[3]), m_[1]),      \
                     pk_min_u16(cvt_pk(v1_[0], v1_[1]), m_[2]), pk_min_u16(cvt_pk(v1_[2], v1_[3]), m_[3])};     \
     }
-#define PMX_GROUP()                                                                                            \
+// one group: the MFMAs of a channel block behind the packing of the next one.  Two copies of this code, for whole groups (no
+// mask) and for the others; where the two paths merge the register allocator may copy accumulators -- PMX_MFS / PMX_SETTLE
+// are written so that this is harmless
+#define PMX_GROUP(MASKED_)                                                                                     \
     {                                                                                                          \
-        PMX_PACKM(pk0, 0, v00, v10) SB();                                                                      \
-        PMX_PACKM(pk1, 1, v01, v11) SB();                                                                      \
+        PMX_PACKM(pk0, 0, v00, v10, MASKED_) SB();                                                             \
+        PMX_PACKM(pk1, 1, v01, v11, MASKED_) SB();                                                             \
         PMX_MFS(pk0, ones_e, sg.a01, sg.g0) SB();                                                              \
-        PMX_PACKM(pk2, 2, v02, v12) SB();                                                                      \
+        PMX_PACKM(pk2, 2, v02, v12, MASKED_) SB();                                                             \
         PMX_MFS(pk1, ones_o, sg.a01, sg.g1) SB();                                                              \
-        PMX_PACKM(pk3, 3, v03, v13) SB();                                                                      \
+        PMX_PACKM(pk3, 3, v03, v13, MASKED_) SB();                                                             \
         PMX_MFS(pk2, ones_e, sg.a23, sg.g2) SB();                                                              \
         PMX_MFS(pk3, ones_o, sg.a23, sg.g3) SB();                                                              \
         PMX_SETTLE(); SB();                                                                                    \
@@ -863,6 +867,14 @@ __device__ __forceinline__ void pool_rows_mx(const TdnnArgs& a, const f32x4& v00
     const u32x4 ncp = {((cb_[0] ^ 0x80000000u) >> 16) * 0x10001u, ((cb_[1] ^ 0x80000000u) >> 16) * 0x10001u,
                        ((cb_[2] ^ 0x80000000u) >> 16) * 0x10001u, ((cb_[3] ^ 0x80000000u) >> 16) * 0x10001u};
     const RowMap& m = a.out_map;
+    // the common case first, with two compares of bookkeeping: the whole group belongs to this block and to the current utterance
+    // (stamps and knock-outs: at ~60 scalar instructions per group the generic walk below cost as much as the arithmetic)
+    if (sc.end_rel >= g0 + 32 && lim_rel >= g0 + 32) {
+        const u32x4 mk = ones_e;                                      // (unused)
+        PMX_GROUP(false)
+        sc.n += 32;
+        return;
+    }
     if (g0 >= lim_rel) return;
     const int n_last = m.n_utts - 1;
     const int g_end = g0 + 32 < lim_rel ? g0 + 32 : lim_rel;
@@ -888,7 +900,7 @@ __device__ __forceinline__ void pool_rows_mx(const TdnnArgs& a, const f32x4& v00
 #define PMX_MK(b_) ((unsigned)(-(int)((lm >> (b_)) & 1u)) & 0xffffu) | ((unsigned)(-(int)((lm >> ((b_) + 1)) & 1u)) << 16)
                 const u32x4 mk = {PMX_MK(0), PMX_MK(2), PMX_MK(16), PMX_MK(18)};
 #undef PMX_MK
-                PMX_GROUP()
+                PMX_GROUP(true)
             }
             sc.n += hi - lo;
         }

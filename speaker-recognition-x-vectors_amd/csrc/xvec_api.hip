@@ -70,6 +70,7 @@ struct xvec_handle {
     void* Wr16[XVEC_NUM_TDNN];         // bf16, K-tile major [n_pad/256][k_pad/64][256][64] (tdnn_pp16.hip: both operands reach LDS by DMA)
     bool use_pp;                       // large-batch bf16 mapping enabled (XVEC_PP=0 disables it: A/B runs)
     int pp_min_tenths;                 // ... from this many tenths of a 64-frame unit per CU on (18; XVEC_PP_MIN_TENTHS: crossover sweeps)
+    int pp_cu_pct;                     // XVEC_PP_CU_PCT (diagnostic): percentage of the CUs the large-batch kernel's grid covers (0 = all)
     void* Wp48[XVEC_NUM_TDNN];         // bf16x3: per chunk W_hi then W_lo fragments (2x the size), fragment-major
     void* Wr48[XVEC_NUM_TDNN];         // bf16x3, K-tile major for tdnn_pp16.hip: per K-tile W_hi | W_lo | W_hi (3x the size of Wr16)
     float* Wp[XVEC_NUM_TDNN];
@@ -189,7 +190,8 @@ struct StageTimer {
 // 300 frames for layers 2-4, 18 for layer 5; the same for bf16x3).  Returns the blocks per 256-channel column, 0 if not.
 int pp_blocks_per_col(const xvec_handle* h, int n_pad, int64_t rows_out) {
     if (!h->use_pp || n_pad % 256 != 0) return 0;
-    const int bpc = h->num_cu / (n_pad / 256);
+    int bpc = h->num_cu / (n_pad / 256);
+    if (h->pp_cu_pct > 0 && h->pp_cu_pct < 100) bpc = (bpc * h->pp_cu_pct + 50) / 100;      // diagnostic knob: fewer, longer row ranges
     const int64_t units = (rows_out + 63) / 64;
     return (bpc >= 1 && units >= bpc && 10 * units >= h->pp_min_tenths * (int64_t)bpc) ? bpc : 0;
 }
@@ -533,6 +535,8 @@ int xvec_create(const xvec_cfg* cfg, xvec_handle** out) {
         h->use_pp = !(p && atoi(p) == 0);
         const char* mt = getenv("XVEC_PP_MIN_TENTHS");
         h->pp_min_tenths = mt && atoi(mt) > 0 ? atoi(mt) : 18;
+        const char* cp = getenv("XVEC_PP_CU_PCT");
+        h->pp_cu_pct = cp ? atoi(cp) : 0;
     }
     h->cin_pad = round_up(cfg->input_size, 4);
     fill_geometry(h, h->geo, 2 * kBK);

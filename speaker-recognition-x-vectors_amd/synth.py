@@ -61,3 +61,14 @@ def make_mfcc(batch: int, frames: int, input_size: int = 24, seed: int = 0) -> n
 def make_lengths(batch: int, lo: int = 200, hi: int = 1000, seed: int = 1234) -> np.ndarray:
     """BASELINE config 3: lengths ~ U{lo..hi}."""
     return np.random.default_rng(seed).integers(lo, hi + 1, batch).astype(np.int32)
+
+
+def make_plda(dim: int = 512, rank: int = 200, seed: int = 21):
+    """A random, well-conditioned PLDA model (mean[D], F[D,R], Sigma[D,D], float64) for the scoring back end's
+    benchmark figure (there is no trained model without VoxCeleb): the shapes the reference's
+    `plda_classifier.setup_plda(rank_f=...)` trains (plda_classifier.py:31-45)."""
+    rng = np.random.default_rng(seed)
+    mean = rng.normal(0, 1, dim)
+    F = rng.normal(0, 1 / np.sqrt(dim), (dim, rank))
+    A = rng.normal(0, 1 / np.sqrt(dim), (dim, dim))
+    return mean, F, A @ A.T + 0.5 * np.eye(dim)

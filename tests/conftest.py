@@ -40,6 +40,34 @@ def assert_parity(got, ref, tol=1e-4, what="", elem_tol=None):
     assert not bad.any(), f"{what}: {int(bad.sum())} elements outside rtol={et}, atol={atol:.3e}"
 
 
+def assert_parity_masked(got, ref, tol, what, elem_tol, exclude, max_excluded=1e-3):
+    """assert_parity with an EXPLICIT list of ill-conditioned elements instead of a widened element-wise tolerance (VERDICT r03
+    item 5): the row-wise norm check runs on everything, the element-wise check at `elem_tol` on every element that is not in
+    `exclude` (bool, same shape), and `exclude` may cover at most `max_excluded` of the elements.  Returns the excluded share."""
+    got = torch.as_tensor(np.asarray(got) if not torch.is_tensor(got) else got).double().cpu()
+    ref = torch.as_tensor(np.asarray(ref) if not torch.is_tensor(ref) else ref).double().cpu()
+    exclude = torch.as_tensor(exclude).cpu().bool()
+    assert got.shape == ref.shape == exclude.shape, f"{what}: shapes {tuple(got.shape)} {tuple(ref.shape)} {tuple(exclude.shape)}"
+    share = float(exclude.double().mean())
+    assert share <= max_excluded, f"{what}: {share:.2e} of the elements excluded as ill-conditioned (limit {max_excluded:.0e})"
+    assert torch.isfinite(got).all(), f"{what}: non-finite values"
+    g2, r2 = got.reshape(-1, got.shape[-1]), ref.reshape(-1, ref.shape[-1])
+    rel = (g2 - r2).norm(dim=1) / r2.norm(dim=1).clamp_min(1e-30)
+    assert rel.max().item() <= tol, f"{what}: row-wise relative error {rel.max().item():.3e} > {tol}"
+    atol = elem_tol * ref.abs().mean().item()
+    bad = ((got - ref).abs() > (atol + elem_tol * ref.abs())) & ~exclude
+    assert not bad.any(), f"{what}: {int(bad.sum())} elements outside rtol={elem_tol}, atol={atol:.3e} ({int(exclude.sum())} excluded)"
+    print(f"[mask] {what}: {int(exclude.sum())} of {exclude.numel()} elements excluded ({share:.2e})")
+    return share
+
+
+def nearly_off_channels(relu_frames, min_on=8):
+    """[U, C] bool: channels of an utterance whose ReLU output (reference tdnn_layer.py:31, before the BatchNorm) is above zero
+    in fewer than `min_on` of its frames [U, T, C].  Their standard deviation hangs on a handful of values near zero -- the
+    fp32 reference disagrees with its own fp64 run there at any relative size -- so they are listed, not tolerated."""
+    return (relu_frames > 0).sum(dim=1) < min_on
+
+
 @pytest.fixture(scope="session")
 def synth():
     import xvector_amd

@@ -44,6 +44,10 @@ def test_bench_line(extra):
         for key in ("bf16_embeddings_per_s", "bf16_roofline_frac", "bf16x3_embeddings_per_s", "ragged_utt_per_s", "ragged_valid_frames_per_s"):
             assert isinstance(cfg[key], float) and cfg[key] > 0, key
         assert cfg["bf16_embeddings_per_s"] > cfg["bf16x3_embeddings_per_s"] > d["value"]   # bf16 matrix rate is 16x the fp32 one
+        # next rows N3 / N4 in the driver's own line
+        for key in ("wave_utt_per_s", "wave_bf16_utt_per_s", "mfcc_us_per_batch", "plda_score_ms_n4874"):
+            assert isinstance(cfg[key], float) and cfg[key] > 0, key
+        assert cfg["wave_bf16_utt_per_s"] > cfg["wave_utt_per_s"] and cfg["mfcc_us_per_batch"] < 500 and cfg["plda_score_ms_n4874"] < 20
     else:
         assert "bf16_embeddings_per_s" not in cfg
 

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import assert_parity
+from conftest import assert_parity, assert_parity_masked
 from test_large_batch_layers_gpu import _model, DEV
 
 pytestmark = pytest.mark.gpu
@@ -60,10 +60,14 @@ def test_random_shapes_large_batch_vs_128x128(engines, synth, gpu_model, precisi
     assert torch.equal(got, m_pp.pooled(x, lengths=lengths)), "repeat run differs"
     old = m_old.pooled(x, lengths=lengths)
     assert m_old.last_dispatch()[1:] == ["tile128"] * 4
-    # (element-wise: one flipped bf16 rounding moves the std of a TWO-frame utterance by up to ~1e-2 of itself; bf16x3's
-    #  2e-4 is the check on the kernels' logic)
-    assert_parity(got, old, tight, f"{precision} pooled B={B} T={T} ragged={ragged}",
-                  elem_tol=2e-2 if precision == "bf16" else 10 * tight)
+    # element-wise at the arithmetic's bar (bf16 2e-2; bf16x3's 2e-4 is the check on the kernels' logic) on every utterance with
+    # at least four pooled frames; the shorter ones (one flipped bf16 rounding moves the std of a TWO-frame utterance by ~1e-2
+    # of itself) are listed explicitly and checked norm-wise only
+    short = torch.zeros_like(got, dtype=torch.bool)
+    if ragged:
+        short[torch.as_tensor([n - 14 < 4 for n in lengths])] = True
+    assert_parity_masked(got, old, tight, f"{precision} pooled B={B} T={T} ragged={ragged}",
+                         2e-2 if precision == "bf16" else 10 * tight, short, max_excluded=0.1)
     assert_parity(m_pp.extract_x_vec(x, lengths=lengths), m_old.extract_x_vec(x, lengths=lengths), tight,
                   f"{precision} x-vectors B={B} T={T} ragged={ragged}", elem_tol=10 * tight)
     # and against the exact fp32 path at the precision's own bar

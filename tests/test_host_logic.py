@@ -299,3 +299,10 @@ def test_traffic_json_is_tied_to_the_built_library():
         for key in sec:
             if key != "source":
                 assert any(key in k for k in full), f"traffic.json[{dtype}] names {key!r}, which the built library does not contain"
+    nxt = tj.get("next_rows")                 # N3 / N4: the MFCC kernel and the fp64 score GEMM
+    if newest >= "r04":
+        assert nxt is not None and f"gpurun_out/{newest}" in nxt["source"]
+        assert any("mfcc512_kernel" in k for k in nxt) and any("gemm_nt_f64_kernel" in k for k in nxt)
+        for key in nxt:
+            if key != "source":
+                assert any(key in k for k in full), f"traffic.json[next_rows] names {key!r}, which the built library does not contain"

@@ -24,7 +24,7 @@ import pytest
 import torch
 
 import xvector_oracle as oracle
-from conftest import assert_parity, float_params
+from conftest import assert_parity, assert_parity_masked, float_params, nearly_off_channels
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -140,11 +140,14 @@ def test_bf16_fused_pooling_layer(gpu_model, sd42, synth, models, B, T):
     #  moves a mean by 1/286 = 3.5e-3 of a value)
     assert_parity(got, old, 1e-3, f"pooled B={B} T={T}: large-batch vs 128x128 kernel", elem_tol=5e-3)
     idx = sorted({0, 1, B // 3, B // 2, B - 2, B - 1})
-    ref = torch.cat([oracle.stat_pool(_oracle_layer(h[j:j + 1].cpu(), p64, 4).double()) for j in idx])
+    frames = torch.cat([_oracle_layer(h[j:j + 1].cpu(), p64, 4).double() for j in idx])
+    ref = oracle.stat_pool(frames)
     assert_parity(got[idx], ref, 1e-2, f"pooled B={B} T={T} vs oracle")
-    # (norm-wise only on the std half alone: a nearly-off channel -- a handful of frames above zero -- carries the
-    #  bf16 rounding of layer 4's output at 5-10 % of its tiny std, in the fp32 reference's own bf16-rounded run too)
-    assert_parity(got[idx][:, 1500:], ref[:, 1500:], 1e-2, "std half alone", elem_tol=0.5)
+    # the std half alone, element by element at the bf16 bar -- except the nearly-off channels (a handful of frames above
+    # zero: they carry the bf16 rounding of layer 4's output at 5-10 % of their tiny std, in the fp32 reference's own
+    # bf16-rounded run too), which are LISTED (at most 0.1 % of the elements), not covered by a wide tolerance
+    off = nearly_off_channels(_pre_bn(frames, sd42, 4))
+    assert_parity_masked(got[idx][:, 1500:], ref[:, 1500:], 1e-2, f"std half alone B={B} T={T}", 2e-2, off)
     # the fp32 kernel's fused pooling on the same input, every utterance
     assert_parity(got, gpu_model.pooled_last_layer(h), 1e-2, "vs fp32 fused pooling")
 
@@ -316,8 +319,10 @@ def test_fp32_every_layer_every_element_at_the_bench_size(gpu_model, sd42, synth
         assert_parity(got, _oracle_layer(h.cpu(), p64, i, key=("chain", 256, 300)), 1e-4, f"fp32 layer {i} B=256 vs oracle")
         if i == 3:
             pooled = gpu_model.pooled_last_layer(got)
-            ref = oracle.stat_pool(_oracle_layer(got.cpu(), p64, 4).double())
+            frames = _oracle_layer(got.cpu(), p64, 4).double()
+            ref = oracle.stat_pool(frames)
             assert_parity(pooled[:, :1500], ref[:, :1500], 1e-4, "fp32 pooled means, B=256")
-            # (element-wise 1e-3 on the stds: one of 384 000 -- a nearly-off channel, a handful of frames above zero -- sits at 1.x e-4)
-            assert_parity(pooled[:, 1500:], ref[:, 1500:], 1e-4, "fp32 pooled stds, B=256", elem_tol=1e-3)
+            # stds at the path's own bar element by element; the nearly-off channels (one of 384 000 sat at 1.x e-4) are listed
+            off = nearly_off_channels(_pre_bn(frames, sd42, 4))
+            assert_parity_masked(pooled[:, 1500:], ref[:, 1500:], 1e-4, "fp32 pooled stds, B=256", 1e-4, off)
         h = got

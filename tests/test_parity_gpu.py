@@ -482,7 +482,7 @@ def test_bf16x3_layers_and_full_size(gpu_model, sd42, synth):
     ws = torch.empty(n, dtype=torch.uint8, device=DEV)
     rc = _hip.lib.xvec_forward(eng.h, C.c_void_p(big.data_ptr()), None, 65535, 16, 6, 2, C.c_void_p(outb.data_ptr()),
                                C.c_void_p(ws.data_ptr()), C.c_size_t(n), None)
-    assert rc == 1 and "bf16x3" in _hip.last_error()
+    assert rc == _hip.ERR_TOO_LARGE and "bf16x3" in _hip.last_error()
 
 
 

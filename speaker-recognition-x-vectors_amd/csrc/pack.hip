@@ -186,6 +186,24 @@ hipError_t launch_fold_bias(const float* W, const float* bias, const float* in_s
     return hipGetLastError();
 }
 
+// Layer 1 of plain bf16 on the streaming kernel (tdnn_first.hip): its copy of the fragment-major weights carries the bias in
+// the two spare k slots k = kpt, kpt + 1 of the padded K -- bf16(b) and bf16(b - bf16(b)); the staged input holds 1.0 there.
+// Element (n, k) of the fragment-major packing: ((n / 32 * ksteps + k / 16) * 64 + n % 32 + 32 * (k / 8 % 2)) * 8 + k % 8.
+__global__ void patch_bias_kslots_kernel(const float* __restrict__ bias, int cout, int kpt, int ksteps, __bf16* __restrict__ Wf) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= cout) return;
+    const float b = bias[n];
+    const __bf16 hi = (__bf16)b, lo = (__bf16)(b - (float)hi);
+    for (int j = 0; j < 2; ++j) {
+        const int k = kpt + j;
+        Wf[((int64_t)((n >> 5) * ksteps + (k >> 4)) * 64 + (n & 31) + 32 * ((k >> 3) & 1)) * 8 + (k & 7)] = j ? lo : hi;
+    }
+}
+hipError_t launch_patch_bias_kslots(const float* bias, const TdnnGeom& geo, void* Wf16, hipStream_t s) {
+    patch_bias_kslots_kernel<<<(geo.cout + 255) / 256, 256, 0, s>>>(bias, geo.cout, geo.kpt, geo.k_pad / 16, static_cast<__bf16*>(Wf16));
+    return hipGetLastError();
+}
+
 // x[B,T,C] -> packed rows out[offsets[u] + t][c_pad] for t < len_u (zero padded channels).
 // un_scale / un_shift (or nullptr): the folded BatchNorm of the layer that PRODUCED x, inverted on the way in --
 // r = (x - shift) / scale, 0 where scale == 0 (such a channel meets zero folded weights) -- for the per-layer entries in

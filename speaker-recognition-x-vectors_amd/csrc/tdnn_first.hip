@@ -1,25 +1,19 @@
 // Layer 1 of the bf16 path (reference tdnn_layer.py:26-60 with context [-2..2] on 24 MFCCs): K = 5 x 24 = 120
 // inputs per frame, 512 outputs -- 0.3 % of the path's flops and 77 MB of bf16 output per 256 x 300-frame batch.
 // It is a streaming kernel, not a GEMM tile problem: in the 128x128 kernel (tdnn_layer.hip) a tile's K loop is
-// two chunks long and a tile costs 8.4k cycles (3.3k K loop, mostly load latency behind two barriers; 2.3k
-// epilogue; 2.8k tile switch) for 1k cycles of MFMA -- 31-33 us, where a plain fill of the same 77.6 MB takes
-// 15-17 us (profiles/diag/src/write_bw.hip).  This kernel: 25-28 us on the same boxes.
+// two chunks long and a tile costs 8.4k cycles for 1k cycles of MFMA -- 31-33 us, where a plain fill of the same
+// 77.6 MB takes 15-17 us (profiles/diag/src/write_bw.hip).
 //
-// Here the weights never move: a wave owns 128 output channels and keeps its 128 x 128 bf16 weight block in
-// registers (32 fragments = 128 VGPRs) for the whole launch; a block of four waves covers the 512 channels of
-// one 32-frame group at a time.  The group's input -- 32 windows of 120 consecutive floats, 96 B apart -- is
-// fetched by the 256 threads together (one 16-wide k-step of one frame each, 64 contiguous bytes), rounded to
-// bf16 and parked in an 8 KiB LDS tile (two tiles: the next group is fetched into registers while this one is
-// multiplied; one barrier per group).  A lane's four accumulators hold FOUR ADJACENT channels (lane r of accumulator cg is
-// channel 4r + cg of the wave's 128: which column of W a lane multiplies is only a matter of which fragment bytes it
-// loaded), so two v_cvt_pk_bf16_f32 make the 8 bytes that belong at column 4r and a store instruction writes two whole
-// 256-byte row segments: 16 store instructions per group and wave (round 3: dwords at column 2r, 32 instructions).  (The transposed product with 16-byte stores per lane, which
-// touches 32 rows x 32 B per instruction, measured the same here; what did cost time was every wave waiting
-// for its stores to be acknowledged at each group's barrier, see XF_LDS_BARRIER.)  No per-tile descriptors,
-// no tile switch; the utterance bookkeeping (input row = output row + 4 x utterance index) is two scalar
-// compares per group on the fixed-length path.
+// Here the weights never move: a wave keeps its block of the 512 x 128 bf16 weight matrix in registers for the whole
+// launch, a block covers the 512 channels of one 32-frame group at a time.  The group's input -- 32 windows of 120
+// consecutive floats, 96 B apart -- is fetched by the block's threads together, rounded to bf16 and parked in an LDS tile
+// (two tiles: the next group is fetched into registers while this one is multiplied; one barrier per group).  No per-tile
+// descriptors, no tile switch; the utterance bookkeeping (input row = output row + 4 x utterance index) is two scalar
+// compares per group on the fixed-length path.  What cost time in the first version was every wave waiting for its stores
+// to be acknowledged at each group's barrier (XF_LDS_BARRIER).  Plain bf16: tdnn_first_kernel (round 4's form is described
+// above it); bf16x3: first3::tdnn_first3_kernel.
 //
-// Shapes: n_pad == 512, one folded tap with k_pad == 128 (input_size * 5 <= 128, rows contiguous: ldx ==
+// Shapes: n_pad == 512, one folded tap with k_pad == 128 (input_size * 5 <= 126 for plain bf16, rows contiguous: ldx ==
 // input_size) and 16-byte aligned rows; run_tdnn falls back to the 128x128 kernel otherwise.
 #include "tdnn_common.h"
 
@@ -40,11 +34,6 @@ __device__ __forceinline__ u32x4 cvt8(const u32x4& lo, const u32x4& hi) {
     return o;
 }
 
-// staged input of one thread: k-step `ks` (16 values) of frame `rr` of the group
-struct Staged {
-    u32x4 q0, q1, q2, q3;                  // 16 floats of the caller's fp32 rows
-};
-
 template <bool RAGGED>
 __device__ __forceinline__ int64_t first_row_of(const RowMap& m, int u) {
     u = __builtin_amdgcn_readfirstlane(u);
@@ -58,8 +47,27 @@ struct Cur {
     int64_t end;
 };
 
+// ---- round 4: one block of EIGHT waves per CU, 64 channels per wave, v_mfma_f32_16x16x32_bf16 -------------------------------
+// What changed against round 3's form (two blocks of four waves x 128 channels, 32x32x16) and why:
+//   * start-up.  Every wave fetched its 32 KB of weight fragments: 512 blocks x 4 waves x 32 KB = 64 MB of L2 reads for 128 KB
+//     of weights, a third of the kernel.  Eight waves of 64 channels hold 16 KB each and a CU has one block: 32 MB.
+//   * the bias rides in the two spare k slots of the padded K = 128 (k = kpt, kpt + 1; the reference's 5 x 24 = 120): the staged
+//     input carries 1.0 there and the weight copy of this kernel (xvec_api.hip, refold: Wp16b) bf16(bias) and
+//     bf16(bias - bf16(bias)) -- the sum is the bias to 2^-17, the products are exact -- so the epilogue has no add;
+//   * the accumulator layout of tdnn_pp16.hip: frames on the registers and lane quads, the channel on the lane, a lane's four
+//     accumulators of a frame on four ADJACENT channels (which column of W a lane multiplies is only a matter of which fragment
+//     bytes it loaded): two v_cvt_pk_bf16_f32, the ReLU on the packed pairs, one 8-byte store = whole 128-byte row segments of
+//     four frames per instruction; 8 store instructions per group and wave (round 3: 32 of 4 bytes).
+// The BatchNorm behind the ReLU (tdnn_layer.py:36-39) is deferred into layer 2's weights (xvec_api.hip, refold).
+constexpr int kRowB16 = 288;               // LDS bytes per frame: 128 bf16 + 32 (72 dwords: the ds_read_b128 A fragments of the sixteen
+constexpr int kTileB16 = 32 * kRowB16;     // lanes of a service group fall on sixteen distinct 4-bank windows)
+
+struct Staged8 {
+    u32x4 q0, q1;                          // 8 floats of the caller's fp32 rows
+};
+
 template <bool RAGGED>
-__device__ __forceinline__ void fetch(const TdnnArgs& a, int64_t g, Cur& cu, int rr, int ks, Staged& st) {
+__device__ __forceinline__ void fetch8(const TdnnArgs& a, int64_t g, Cur& cu, int rr, int sk, Staged8& st) {
     const RowMap& m = a.out_map;
     const int64_t m0 = g * 32;
     const int n_last = m.n_utts - 1;
@@ -67,8 +75,7 @@ __device__ __forceinline__ void fetch(const TdnnArgs& a, int64_t g, Cur& cu, int
         cu.u = __builtin_amdgcn_readfirstlane(cu.u + 1);
         cu.end = first_row_of<RAGGED>(m, cu.u + 1);
     }
-    // boundaries inside the group: frame rr lies c utterances past cu.u
-    int c = 0;
+    int c = 0;                             // boundaries inside the group: frame rr lies c utterances past cu.u
     {
         int u = cu.u;
         int64_t nxt = cu.end;
@@ -78,63 +85,51 @@ __device__ __forceinline__ void fetch(const TdnnArgs& a, int64_t g, Cur& cu, int
             nxt = first_row_of<RAGGED>(m, u + 1);
         }
     }
-    constexpr int ES = 4;                  // the input rows are the caller's fp32 MFCCs, rounded to bf16 in park()
-    // descriptor at the group's first input row (64-bit), bounded by the end of the caller's tensor: reads past
-    // it return zeros; the lane offset is small (a group's rows + the utterances it skips)
+    // descriptor at the group's first input row (64-bit), bounded by the end of the caller's tensor: reads past it return
+    // zeros; the lane offset is small (a group's rows + the utterances it skips)
     const int64_t row0 = m0 + (int64_t)cu.u * a.span;
-    const int64_t total = a.x_bytes ? a.x_bytes : a.x_rows * (int64_t)a.ldx * ES;
-    const __amdgpu_buffer_rsrc_t xr = make_rsrc_bounded(a.X, row0 * a.ldx * ES, total);
-    const int voff = ((rr + c * a.span) * a.ldx + 16 * ks) * ES;
+    const int64_t total = a.x_bytes ? a.x_bytes : a.x_rows * (int64_t)a.ldx * 4;
+    const __amdgpu_buffer_rsrc_t xr = make_rsrc_bounded(a.X, row0 * a.ldx * 4, total);
+    const int voff = ((rr + c * a.span) * a.ldx + 8 * sk) * 4;
     st.q0 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, voff, 0, 0));
     st.q1 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, voff, 16, 0));
-    st.q2 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, voff, 32, 0));
-    st.q3 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, voff, 48, 0));
 }
 
-// round to bf16, blank the K tail (values past kpt belong to the next frame and meet zero weights, but
-// 0 x Inf is not 0) and park the 32 bytes in the LDS tile
-__device__ __forceinline__ void park(const TdnnArgs& a, char* tile, int rr, int ks, const Staged& st) {
-    u32x4 lo = cvt8(st.q0, st.q1), hi = cvt8(st.q2, st.q3);
-    const int k0 = 16 * ks;
-    if (k0 + 16 > a.kpt) {                 // only the last k-step(s) of a row: pairs of bf16 per dword
+// round to bf16, blank the K tail (values past kpt belong to the next frame and meet zero weights, but 0 x Inf is not 0), put
+// 1.0 | 1.0 into the bias slots k = kpt, kpt + 1 (one aligned dword: kpt is a multiple of 4) and park the 16 bytes
+__device__ __forceinline__ void park8(const TdnnArgs& a, char* tile, int rr, int sk, const Staged8& st) {
+    u32x4 o = cvt8(st.q0, st.q1);
+    const int k0 = 8 * sk;
+    if (k0 + 8 > a.kpt) {
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
             const int k = k0 + 2 * d;
-            if (k >= a.kpt) lo[d] = 0u; else if (k + 1 >= a.kpt) lo[d] &= 0xffffu;
-            if (k + 8 >= a.kpt) hi[d] = 0u; else if (k + 9 >= a.kpt) hi[d] &= 0xffffu;
+            if (k == a.kpt) o[d] = 0x3f803f80u;
+            else if (k > a.kpt) o[d] = 0u;
         }
     }
-    *reinterpret_cast<u32x4*>(tile + rr * kRowB + ks * 32) = lo;
-    *reinterpret_cast<u32x4*>(tile + rr * kRowB + ks * 32 + 16) = hi;
+    *reinterpret_cast<u32x4*>(tile + rr * kRowB16 + sk * 16) = o;
 }
 
 template <bool RAGGED>
-__global__ __launch_bounds__(256, 2) void tdnn_first_kernel(const TdnnArgs a) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * kTileB + kConstFloats * 4];
-    float* cst = reinterpret_cast<float*>(smem + 2 * kTileB);
+__global__ __launch_bounds__(512) void tdnn_first_kernel(const TdnnArgs a) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * kTileB16];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably uniform: scalar fragment offsets
-    const int r = lane & 31, h = lane >> 5;
-    for (int i = tid; i < 512; i += 256) {
-        cst[i] = a.bias[i];
-        cst[512 + i] = a.scale[i];
-        cst[1024 + i] = a.shift[i];
-    }
-    // this wave's weights: channels [128*wave, +128).  Accumulator cg, lane r <-> channel
-    //   ch = 128*wave + 4*r + cg:
-    // a lane's four accumulators hold FOUR adjacent channels of a frame, which the epilogue writes as one 8-byte piece (which
-    // column of W a lane multiplies is only a matter of which fragment bytes it loaded).  The fragment-major packing (pack.hip)
-    // keeps W[32*ct + l][16*ks + 8*h ..+7] at ((ct*8 + ks)*64 + l + 32*h)*16 B
-    u32x4 wf[4][8];
+    const int c = lane & 15, kq = lane >> 4;
+    // this wave's weights: channels [64*wave, +64).  Accumulator (frame block, cb), lane c <-> channel 64*wave + 4*c + cb.  B operand
+    // of k-step s (32 wide): lane (c, kq) holds k = 32 s + 8 kq ..+7.  The fragment-major packing (pack.hip) keeps
+    // W[32*ct + l][16*ks + 8*h ..+7] at ((ct*8 + ks)*64 + l + 32*h)*16 B
+    u32x4 wf[4][4];
     {
         const __amdgpu_buffer_rsrc_t wr = make_rsrc(a.Wf);
 #pragma unroll
-        for (int cg = 0; cg < 4; ++cg) {
-            const int ch = 128 * wave + 4 * r + cg;
-            const int voff = ((ch >> 5) * 8 * 64 + (ch & 31) + 32 * h) * 16;
+        for (int cb = 0; cb < 4; ++cb) {
+            const int n = 64 * wave + 4 * c + cb;
+            const int voff = ((n >> 5) * 8 * 64 + (n & 31) + 32 * (kq & 1)) * 16 + (kq >> 1) * 1024;
 #pragma unroll
-            for (int ks = 0; ks < 8; ++ks)
-                wf[cg][ks] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wr, voff, ks * 1024, 0));
+            for (int s = 0; s < 4; ++s)
+                wf[cb][s] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wr, voff, 2 * s * 1024, 0));
         }
     }
     // contiguous range of 32-frame groups per block
@@ -144,51 +139,52 @@ __global__ __launch_bounds__(256, 2) void tdnn_first_kernel(const TdnnArgs a) {
     Cur cu;
     cu.u = __builtin_amdgcn_readfirstlane(utt_of_row(a.out_map, g_begin * 32));
     cu.end = first_row_of<RAGGED>(a.out_map, cu.u + 1);
-    const int rr = tid >> 3, sks = tid & 7;        // staging: frame rr, k-step sks
+    const int rr = tid >> 4, sk = tid & 15;        // staging: frame rr, half k-step sk (8 floats)
     // Two groups of look-ahead: loads and stores share the wave's in-order vmcnt counter, so waiting for loads
-    // issued AFTER a group's 32 stores would wait for those stores to be acknowledged by memory (several us at
-    // full write rate: 6 us per group, no faster than the 128x128 kernel).  The loads of group g+2 are issued
-    // before the stores of group g, and the wait for group g+1's loads leaves the newer operations in flight.
-    Staged sa, sb;
-    fetch<RAGGED>(a, g_begin, cu, rr, sks, sa);
-    park(a, smem, rr, sks, sa);
-    if (g_begin + 1 < g_end) fetch<RAGGED>(a, g_begin + 1, cu, rr, sks, sb);
-    __syncthreads();                               // constants + tile 0 visible
+    // issued AFTER a group's stores would wait for those stores to be acknowledged by memory (several us at
+    // full write rate).  The loads of group g+2 are issued before the stores of group g, and the wait for group
+    // g+1's loads leaves the newer operations in flight.
+    Staged8 sa, sb;
+    fetch8<RAGGED>(a, g_begin, cu, rr, sk, sa);
+    park8(a, smem, rr, sk, sa);
+    if (g_begin + 1 < g_end) fetch8<RAGGED>(a, g_begin + 1, cu, rr, sk, sb);
+    __syncthreads();                               // tile 0 visible
 
-    const char* frag = smem + r * kRowB + 16 * h;  // A operand of lane (r, h): frame r, k = 16*ks + 8*h ..+7
-    // bias of this lane's four channels (128*wave + 4r ..+3)
-    const float4 bi = *reinterpret_cast<const float4*>(cst + 128 * wave + 4 * r);
-    // accumulator element e of lane (r, h): frame (e&3) + 8*(e>>2) + 4*h; the lane's 8 bytes sit at column 4r
-    const int y_voff = (4 * h * a.ldy + 128 * wave + 4 * r) * 2;
-    // __syncthreads() is `s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier`: it would hold every wave until its 32 stores
+    const char* frag = smem + c * kRowB16 + 16 * kq;   // A operand of lane (c, kq): frame 16 fb + c, k = 32 s + 8 kq ..+7
+    // accumulator register e of lane (c, q = kq): frame 16 fb + 4 q + e; the lane's 8 bytes sit at column 64*wave + 4c
+    const int y_voff = (4 * kq * a.ldy + 64 * wave + 4 * c) * 2;
+    // __syncthreads() is `s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier`: it would hold every wave until its stores
     // of the group are acknowledged by memory.  Only the LDS traffic has to be ordered here.
 #define XF_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#define XF_MF(x_, w_, acc_) acc_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, x_), __builtin_bit_cast(bf16x8, w_), acc_, 0, 0, 0);
     // one group: MFMAs on LDS tile `buf_`, park the staged group g+1 (ST_PARK) into the other tile, fetch group
     // g+2 into the set that was parked last time (ST_FETCH), epilogue + stores
 #define XF_GROUP(g_, buf_, ST_PARK, ST_FETCH)                                                                     \
     {                                                                                                             \
-        if ((g_) + 2 < g_end) fetch<RAGGED>(a, (g_) + 2, cu, rr, sks, ST_FETCH);                           \
-        f32x16 acc[4];                                                                                            \
-        _Pragma("unroll") for (int cg = 0; cg < 4; ++cg)                                                          \
-            _Pragma("unroll") for (int e = 0; e < 16; ++e) acc[cg][e] = 0.f;                                      \
-        const char* tile = frag + (buf_) * kTileB;                                                                \
-        _Pragma("unroll") for (int ks = 0; ks < 8; ++ks) {                                                        \
-            const u32x4 xf = *reinterpret_cast<const u32x4*>(tile + ks * 32);                                     \
-            _Pragma("unroll") for (int cg = 0; cg < 4; ++cg)                                                      \
-                acc[cg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, xf),                 \
-                                                                  __builtin_bit_cast(bf16x8, wf[cg][ks]), acc[cg], 0, 0, 0); \
+        if ((g_) + 2 < g_end) fetch8<RAGGED>(a, (g_) + 2, cu, rr, sk, ST_FETCH);                                  \
+        f32x4 acc[2][4];                                                                                          \
+        _Pragma("unroll") for (int fb = 0; fb < 2; ++fb)                                                          \
+            _Pragma("unroll") for (int cb = 0; cb < 4; ++cb) acc[fb][cb] = f32x4{0.f, 0.f, 0.f, 0.f};             \
+        const char* tile = frag + (buf_) * kTileB16;                                                              \
+        _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                           \
+            const u32x4 x0 = *reinterpret_cast<const u32x4*>(tile + s * 64);                                      \
+            const u32x4 x1 = *reinterpret_cast<const u32x4*>(tile + 16 * kRowB16 + s * 64);                       \
+            _Pragma("unroll") for (int cb = 0; cb < 4; ++cb) {                                                    \
+                XF_MF(x0, wf[cb][s], acc[0][cb]) XF_MF(x1, wf[cb][s], acc[1][cb])                                 \
+            }                                                                                                     \
         }                                                                                                         \
-        if ((g_) + 1 < g_end) park(a, smem + ((buf_) ^ 1) * kTileB, rr, sks, ST_PARK);                     \
-        /* bias + ReLU (tdnn_layer.py:30-31; the BatchNorm behind it, :36-39, is deferred into layer 2's weights: */ \
-        /* xvec_api.hip, refold); rows of the group at g*32 (the row buffer is padded past the last valid frame) */ \
+        if ((g_) + 1 < g_end) park8(a, smem + ((buf_) ^ 1) * kTileB16, rr, sk, ST_PARK);                          \
+        /* ReLU (tdnn_layer.py:31; bias inside the products, BatchNorm deferred); rows of the group at g*32 (the */ \
+        /* row buffer is padded past the last valid frame) */                                                     \
         const __amdgpu_buffer_rsrc_t yr = make_rsrc(static_cast<char*>(a.Y) + (g_) * 32 * (int64_t)a.ldy * 2);    \
-        _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                                          \
-            u32x2v pk = {__builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{acc[0][e] + bi.x, acc[1][e] + bi.y}, bf16x2)), \
-                         __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{acc[2][e] + bi.z, acc[3][e] + bi.w}, bf16x2))}; \
-            asm("v_pk_max_i16 %0, %1, 0" : "=v"(pk[0]) : "v"(pk[0]));   /* ReLU of the packed pair (tdnn_pp16.hip, relu_pk_bf16) */ \
-            asm("v_pk_max_i16 %0, %1, 0" : "=v"(pk[1]) : "v"(pk[1]));                                             \
-            __builtin_amdgcn_raw_buffer_store_b64(pk, yr, y_voff, ((e & 3) + 8 * (e >> 2)) * a.ldy * 2, 0);      \
-        }                                                                                                         \
+        _Pragma("unroll") for (int fb = 0; fb < 2; ++fb)                                                          \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                       \
+                u32x2v pk = {__builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{acc[fb][0][e], acc[fb][1][e]}, bf16x2)), \
+                             __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{acc[fb][2][e], acc[fb][3][e]}, bf16x2))}; \
+                asm("v_pk_max_i16 %0, %1, 0" : "=v"(pk[0]) : "v"(pk[0]));   /* ReLU of the packed pair (tdnn_pp16.hip, relu_pk_bf16) */ \
+                asm("v_pk_max_i16 %0, %1, 0" : "=v"(pk[1]) : "v"(pk[1]));                                         \
+                __builtin_amdgcn_raw_buffer_store_b64(pk, yr, y_voff, (16 * fb + e) * a.ldy * 2, 0);              \
+            }                                                                                                     \
         XF_LDS_BARRIER() /* the other tile is written, this one read by every wave */                            \
     }
     typedef float f32x2v __attribute__((ext_vector_type(2)));
@@ -198,6 +194,7 @@ __global__ __launch_bounds__(256, 2) void tdnn_first_kernel(const TdnnArgs a) {
         if (g + 1 < g_end) XF_GROUP(g + 1, 1, sa, sb)
     }
 #undef XF_GROUP
+#undef XF_MF
 #undef XF_LDS_BARRIER
 }
 
@@ -375,15 +372,15 @@ hipError_t launch_tdnn_first3(const TdnnArgs& a, int num_cu, hipStream_t s) {
 }
 
 bool tdnn_first_applicable(const TdnnArgs& a) {
-    return a.ldy == 512 && a.k_pad == 128 && a.n_taps == 1 && a.kpt <= 128 && a.terms == 1 && (a.ldx * 4) % 16 == 0 &&
-           (reinterpret_cast<uintptr_t>(a.X) & 15) == 0 && a.groups_total > 0;
+    // (kpt + 2 <= 128: two spare k slots carry the bias; kpt a multiple of 4 follows from the aligned, contiguous rows)
+    return a.ldy == 512 && a.k_pad == 128 && a.n_taps == 1 && a.kpt <= 126 && a.kpt % 4 == 0 && a.terms == 1 &&
+           (a.ldx * 4) % 16 == 0 && (reinterpret_cast<uintptr_t>(a.X) & 15) == 0 && a.groups_total > 0;
 }
 
 hipError_t launch_tdnn_first(const TdnnArgs& a, int num_cu, hipStream_t s) {
-    const int64_t want = 2 * (int64_t)num_cu;      // one block per CU measured 30 us against 28
-    const int grid = (int)(a.groups_total < want ? a.groups_total : want);
-    if (a.out_map.offsets != nullptr) first::tdnn_first_kernel<true><<<grid, 256, 0, s>>>(a);
-    else first::tdnn_first_kernel<false><<<grid, 256, 0, s>>>(a);
+    const int grid = (int)(a.groups_total < num_cu ? a.groups_total : num_cu);       // one block of eight waves per CU
+    if (a.out_map.offsets != nullptr) first::tdnn_first_kernel<true><<<grid, 512, 0, s>>>(a);
+    else first::tdnn_first_kernel<false><<<grid, 512, 0, s>>>(a);
     return hipGetLastError();
 }
 

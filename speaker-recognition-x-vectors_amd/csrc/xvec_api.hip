@@ -67,6 +67,7 @@ struct xvec_handle {
     TdnnGeom geo[XVEC_NUM_TDNN];
     TdnnGeom geo16[XVEC_NUM_TDNN];     // bf16 packing of layers 2-5: 64-element chunks (layer 1 stays fp32)
     void* Wp16[XVEC_NUM_TDNN];         // bf16, fragment-major
+    void* Wp16b;                       // layer 1 only: the same with the bias in the two spare k slots (tdnn_first.hip)
     void* Wr16[XVEC_NUM_TDNN];         // bf16, K-tile major [n_pad/256][k_pad/64][256][64] (tdnn_pp16.hip: both operands reach LDS by DMA)
     bool use_pp;                       // large-batch bf16 mapping enabled (XVEC_PP=0 disables it: A/B runs)
     int pp_min_tenths;                 // ... from this many tenths of a 64-frame unit per CU on (18; XVEC_PP_MIN_TENTHS: crossover sweeps)
@@ -300,6 +301,7 @@ int run_tdnn(xvec_handle* h, int layer, TdnnVariant v, const void* X, int ldx, i
         return XVEC_OK;
     }
     if (h->use_pp && layer == 0 && v == TdnnVariant::kBf16FirstSrc32 && tdnn_first_applicable(a)) {
+        a.Wf = h->Wp16b;
         HIP_TRY(launch_tdnn_first(a, h->num_cu, s));
         h->last_kernel[layer] = d.kernel = XVEC_KERNEL_FIRST;
         return XVEC_OK;
@@ -326,6 +328,10 @@ int refold(xvec_handle* h, int layer, hipStream_t s) {
     HIP_TRY(launch_pack_tdnn_bf16(h->Wraw[layer], sc, g, h->Wp16[layer], s));
     HIP_TRY(launch_pack_tdnn_rows_bf16(h->Wraw[layer], sc, g, h->Wr16[layer], s));
     HIP_TRY(launch_fold_bias(h->Wraw[layer], h->braw[layer], sh, g, h->vec16[layer], s));
+    if (layer == 0 && g.kpt + 2 <= g.k_pad) {      // the streaming kernel's copy: bias in the spare k slots
+        HIP_TRY(launch_pack_tdnn_bf16(h->Wraw[layer], nullptr, g, h->Wp16b, s));
+        HIP_TRY(launch_patch_bias_kslots(h->braw[layer], g, h->Wp16b, s));
+    }
     h->folded[layer] = true;
     return XVEC_OK;
 }
@@ -545,6 +551,7 @@ int xvec_create(const xvec_cfg* cfg, xvec_handle** out) {
         const TdnnGeom& g = h->geo[i];
         if (hipMalloc(&h->Wp16[i], (size_t)h->geo16[i].n_pad * h->geo16[i].k_pad * 2) != hipSuccess ||
             hipMalloc(&h->Wr16[i], (size_t)h->geo16[i].n_pad * h->geo16[i].k_pad * 2) != hipSuccess ||
+            (i == 0 && hipMalloc(&h->Wp16b, (size_t)h->geo16[i].n_pad * h->geo16[i].k_pad * 2) != hipSuccess) ||
             hipMalloc(&h->Wp48[i], (size_t)h->geo16[i].n_pad * h->geo16[i].k_pad * 2 * 2) != hipSuccess ||
             hipMalloc(&h->Wr48[i], (size_t)h->geo16[i].n_pad * h->geo16[i].k_pad * 2 * 3) != hipSuccess ||
             hipMalloc(reinterpret_cast<void**>(&h->Wp[i]), (size_t)g.n_pad * g.k_pad * 4) != hipSuccess ||
@@ -595,6 +602,7 @@ void xvec_destroy(xvec_handle* h) {
         if (h->braw[i]) (void)hipFree(h->braw[i]);
         if (h->vec16[i]) (void)hipFree(h->vec16[i]);
     }
+    if (h->Wp16b) (void)hipFree(h->Wp16b);
     for (int i = 0; i < 3; ++i) {
         if (h->affW[i]) (void)hipFree(h->affW[i]);
         if (h->affB[i]) (void)hipFree(h->affB[i]);

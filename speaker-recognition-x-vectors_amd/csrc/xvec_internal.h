@@ -131,7 +131,9 @@ hipError_t launch_tdnn(const TdnnArgs& a, TdnnVariant v, hipStream_t s);
 hipError_t launch_tdnn_pp16(const TdnnArgs& a, bool pool, hipStream_t s);
 // Layer 1 of the bf16 path as a streaming kernel (tdnn_first.hip): weights resident in registers, 16-byte stores.
 // Reads TdnnArgs as the 128x128 kernel does (Wf = fragment-major bf16 weights); X holds the caller's fp32 rows.
+// (Wf = the layer's fragment-major copy WITH the bias in k slots kpt, kpt + 1: launch_patch_bias_kslots)
 bool tdnn_first_applicable(const TdnnArgs& a);
+hipError_t launch_patch_bias_kslots(const float* bias, const TdnnGeom& geo, void* Wf16, hipStream_t s);
 hipError_t launch_tdnn_first(const TdnnArgs& a, int num_cu, hipStream_t s);
 // ... and of the bf16x3 path: terms == 2, Wf = the bf16x3 fragment stream, Y = two bf16 planes y_plane_bytes apart; X the caller's fp32 rows
 bool tdnn_first3_applicable(const TdnnArgs& a);

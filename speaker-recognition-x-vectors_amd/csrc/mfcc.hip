@@ -42,6 +42,10 @@ struct MfccDev {
     const float* f_fb;      // [2 filter tiles][16 bin groups][64 lanes][4]
     const float* f_dct;     // [2 cepstrum tiles][2 filter groups][64 lanes][4]
     int f_n0, f_lo0, f_n1, f_lo1;   // bin groups with a non-zero weight: tile 0 [lo0, lo0+n0), tile 1 [lo1, lo1+n1)
+    // frame index -> (utterance, frame of the utterance) without a division: b = (g * fr_magic) >> (31 + fr_shift), exact for
+    // g < 2^31 (fr_magic = ceil(2^(31 + fr_shift) / n_frames), fr_shift = ceil(log2 n_frames); set per launch by xvec_mfcc)
+    unsigned fr_magic;
+    int fr_shift;
 };
 
 __device__ __forceinline__ unsigned bitrev(unsigned v, int bits) { return __brev(v) >> (32 - bits); }
@@ -228,8 +232,9 @@ namespace fft512 {
 
 constexpr int kTile = 16;                   // frames per block pass
 constexpr int kEx = 576;                    // complex slots of a wave's exchange region (8 x 72)
-constexpr int kPS = 260;                    // floats per row of the power-spectrum tile (256 + 4: b128 reads spread over the banks)
-constexpr int kLS = 36;                     // floats per row of the log-mel tile
+constexpr int kPS = 264;                    // floats per row of the power-spectrum tile (256 + 8) and of the log-mel tile: row strides of 8 mod 64
+constexpr int kLS = 40;                     // dwords put the sixteen lanes of a ds_read_b128 service group (rows r, lane quads q: 16-byte
+                                            // fragments at 4 q) on sixteen distinct 4-bank windows (260 / 36: one 2-way conflict per group)
 constexpr int kMaxItems = 5;                // (filter tile, bin group) products per wave: 20 per block (the default filterbank has 18)
 constexpr int kLdsFloats = 4 * kEx * 2 + kTile * kPS + kTile * kLS + 2 * kTile + 2 * 56;
 typedef float f32x4v __attribute__((ext_vector_type(4)));
@@ -269,6 +274,27 @@ __device__ __forceinline__ c32 cmul(c32 x, c32 w) {
     asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(x), "v"(w));
     asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(x), "v"(w), "v"(t));
     return r;
+}
+
+// sum over the 64 lanes, in every lane, without LDS: within each row of 16 lanes by DPP (mirror, half mirror, the two quad
+// permutations), across the four rows by v_permlane16_swap / v_permlane32_swap of the value with itself
+__device__ __forceinline__ float wave_sum(float v) {
+#define MF_DPP_ADD(ctrl_) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl_, 0xf, 0xf, false));
+    MF_DPP_ADD(0x140)          // row_mirror:        lane i <-> 15 - i
+    MF_DPP_ADD(0x141)          // row_half_mirror:   i <-> 7 - i within each half row
+    MF_DPP_ADD(0xb1)           // quad_perm [1,0,3,2]
+    MF_DPP_ADD(0x4e)           // quad_perm [2,3,0,1]
+#undef MF_DPP_ADD
+    // the two swaps as inline asm: given the SAME value twice and a use of BOTH results, hipcc 7.2 folds the sum of the two
+    // results of __builtin_amdgcn_permlane16_swap / permlane32_swap into 2 x the first one in this kernel (seen as log-energies
+    // off by a few per cent; with two different operands the builtins are fine).  s_nop 1: the two wait states between a vector
+    // write of an operand and the swap, which the compiler adds for the builtin.
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));          // rows {0|0|2|2}, {1|1|3|3}
+    a += b;
+    b = a;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));          // halves {lo|lo}, {hi|hi}
+    return a + b;
 }
 
 // natural-order DFT-8, forward sign (W_8 = exp(-2 pi i / 8)): 28 packed instructions
@@ -319,7 +345,9 @@ __device__ __forceinline__ FrameSrc frame_src(const float* __restrict__ sig, int
                                               int64_t total_frames, int64_t gframe, const MfccDev& d, int used) {
     const bool live = gframe < total_frames;
     const unsigned gf = live ? (unsigned)gframe : 0u;          // the launcher keeps total_frames below 2^31
-    const unsigned b = gf / (unsigned)n_frames;
+    // (a 32-bit division by a run-time divisor is ~30 scalar instructions, four times per wave and tile: 270 SALU instructions
+    //  per wave and tile in round 3's counters; by the launch's magic number it is a multiply-high and a shift)
+    const unsigned b = (unsigned)(((unsigned long long)gf * d.fr_magic) >> (31 + d.fr_shift));
     const int64_t start = (int64_t)(gf - b * (unsigned)n_frames) * d.frame_step;
     const int64_t left = n_samples - start;                    // samples from `start` to the end of the signal
     const int lim = live && left > 0 ? (int)(left < used ? left : used) : 0;   // (a frame step longer than the frame can start past the end)
@@ -430,18 +458,21 @@ __global__ __launch_bounds__(256, 4) void mfcc512_kernel(const float* __restrict
 #pragma unroll
             for (int c = 0; c < 8; ++c) x[c] = ex[hi * 72 + lo * 9 + c];   // lane = 8 k0 + k1
             dft8(x);                                                // over c -> k2
-            // Z[k0 + 8 k1 + 64 k2] at slot k + (k >> 3)
+            // Z[k = k0 + 8 k1 + 64 k2] at slot k + 2 (k >> 4) = 72 k2 + 8 k1 + 2 (k1 >> 1) + k0: this store and the split's reads
+            // below (k and 512 - k, lanes dealt to k so that the two 16-lane halves of a 32-lane service group read runs 128
+            // bins apart) then cost 8 LDS cycles of bank conflicts per pair of frames in all, by the guide's bank rules
+            // (round 3: slot k + (k >> 3) and k = lane + 64 it: 48 -- SQ_LDS_BANK_CONFLICT was 16.5 % of the LDS cycles)
 #pragma unroll
-            for (int k2 = 0; k2 < 8; ++k2) ex[k2 * 72 + lo * 9 + hi] = x[k2];
+            for (int k2 = 0; k2 < 8; ++k2) ex[k2 * 72 + lo * 8 + 2 * (lo >> 1) + hi] = x[k2];
             wave_lds_sync();
             // (frames past the end of the batch have empty descriptors: the loads return zeros)
             // split the two spectra: A = (Z[k] + conj Z[N-k]) / 2, B = (Z[k] - conj Z[N-k]) / (2i); power, energies
             float ea = 0.f, eb = 0.f;
 #pragma unroll
             for (int it = 0; it < 5; ++it) {
-                const int k = it < 4 ? lane + 64 * it : 256;
+                const int k = it < 4 ? (lane & 15) + 16 * it + 64 * (lane >> 5) + 128 * ((lane >> 4) & 1) : 256;
                 const int m = (512 - k) & 511;
-                const c32 p = ex[k + (k >> 3)], z = ex[m + (m >> 3)];
+                const c32 p = ex[k + 2 * (k >> 4)], z = ex[m + 2 * (m >> 4)];
                 const c32 sa2 = cadd_conj(p, z), sb2 = csub_conj(p, z);   // 2A, 2iB
                 const c32 qa = sa2 * sa2, qb = sb2 * sb2;
                 const float pa = (qa.x + qa.y) * scale_a, pb = (qb.x + qb.y) * scale_b;
@@ -455,11 +486,8 @@ __global__ __launch_bounds__(256, 4) void mfcc512_kernel(const float* __restrict
                     eb += pb;
                 }
             }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                ea += __shfl_xor(ea, o);
-                eb += __shfl_xor(eb, o);
-            }
+            ea = wave_sum(ea);                                     // (vector-ALU cross-lane adds: __shfl_xor is six LDS round trips per value)
+            eb = wave_sum(eb);
             if (lane == 0) {
                 en[par * kTile + r0] = ea == 0.f ? kEps : ea;
                 en[par * kTile + r0 + 1] = eb == 0.f ? kEps : eb;
@@ -736,8 +764,12 @@ int xvec_mfcc(xvec_mfcc_plan* p, const float* signal, int32_t B, int64_t n_sampl
     if (p->fast && total_frames < (int64_t(1) << 31) - fft512::kTile) {
         const int n_tiles = (int)((total_frames + fft512::kTile - 1) / fft512::kTile);
         const int grid = std::min(n_tiles, 4 * p->num_cu);
+        MfccDev dv = p->dev;
+        dv.fr_shift = 0;
+        while ((1u << dv.fr_shift) < (unsigned)n_frames) ++dv.fr_shift;
+        dv.fr_magic = (unsigned)((((unsigned long long)1 << (31 + dv.fr_shift)) + n_frames - 1) / (unsigned)n_frames);
         fft512::mfcc512_kernel<<<grid, 256, 0, static_cast<hipStream_t>(stream)>>>(signal, n_samples, n_frames, total_frames,
-                                                                              n_tiles, p->dev, out);
+                                                                              n_tiles, dv, out);
         if (hipGetLastError() != hipSuccess) return mfail(XVEC_ERR_HIP, "mfcc kernel launch failed");
         return XVEC_OK;
     }

@@ -1,50 +1,34 @@
-// Frame-level TDNN layer, bf16 operands / fp32 accumulation, for the large batches of the bf16 path
-// (BASELINE configs[4]) -- the mapping of tdnn_pp.hip on v_mfma_f32_16x16x32_bf16 instead of
-// v_mfma_f32_32x32x16_bf16, at the SAME wave output tile (MR x 32 frames x 64 channels), the same LDS image,
-// DMA schedule, barriers and counted waits.  Why: the bf16 path is power-limited on this chip and the
-// clock the chip holds under load depends on the MFMA shape (MI355X_MICROARCH.md, DVFS give-back item 7: ~1.12-1.15x
-// the FLOP/s on random data at equal cycles per FLOP).  What differs from tdnn_pp.hip:
-//   * fragments: lane (c = l & 15, q = l >> 4) reads row 16*fb + c of a 32-row block, 16-byte chunk 4*s + q of
-//     k-step s (two k-steps of 32 per K-tile); the XOR swizzle (row >> 1) & 7 of the image is conflict-free for this
-//     ds_read_b128 pattern too (checked per 16-lane service group);
-//   * accumulators: per 32-frame acc row 2 frame blocks x 4 channel blocks of 16x16 (4 registers each: frame
-//     4*q + e of the block, channel c of the channel block);
-//   * weights: row 16*cb + c of a wave's 64-channel block holds channel 4*c + cb (pack.hip, shape 16), so a lane's
-//     four accumulators of a frame hold four ADJACENT channels: the store epilogue writes 8 bytes per lane = whole
-//     128-byte row segments of four frames per instruction; the pooling epilogue reduces over the four lane quads
-//     with v_permlane16_swap + v_permlane32_swap and writes all three planes of a partial with one 16-byte store.
-// Template flag X3 (round 3): the bf16x3 arithmetic (fp32 values as hi + lo bf16 planes) on the same tiles -- the K
-// loop is untouched; kstep() walks three K-tiles per 64-channel slab (hi x W_hi, hi x W_lo, lo plane x W_hi), the store
-// epilogue writes both planes, and the accumulators start at zero with the bias added in the epilogue.
-// The rest of this header is tdnn_pp.hip's.
+// Frame-level TDNN layer, bf16 operands / fp32 accumulation, for the large batches of the bf16 path (BASELINE configs[4]) and,
+// with the template flag X3, of bf16x3 (fp32 values as hi + lo bf16 planes).  The same implicit GEMM as
+// tdnn_layer.hip (reference tdnn_layer.py:26-41: context gather -> Linear -> ReLU -> eval BatchNorm, optional fused statistics
+// pooling, main.py:59-63) on a machine mapping built for the bf16 matrix rate, on v_mfma_f32_16x16x32_bf16.
 //
-// The same implicit GEMM as tdnn_layer.hip (tdnn_layer.py:26-41 of the
-// reference: context gather -> Linear -> ReLU -> eval BatchNorm, optional fused statistics pooling,
-// main.py:59-63) with a machine mapping built for the bf16 matrix rate.
-//
-// Why a second mapping.  The 128x128-tile kernel of tdnn_layer.hip moves 512 B from L2 per
-// v_mfma_f32_32x32x16_bf16; at the bf16 rate that is ~52 B/clk per CU against the ~64 B/clk the
-// L2 -> CU path delivers, so loads and MFMAs add up instead of overlapping (DESIGN.md 8 [4]).  Here:
-//   * ONE 512-thread block per CU, tile = up to 256 frames x 256 channels, K in 64-wide tiles
-//     (128-byte rows): 256 B per MFMA, half the L2 traffic.
-//   * both operands go global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds: no staging registers,
-//     no ds_write), 1-KiB pieces of 8 rows x 128 B; the 16-byte-chunk XOR swizzle that makes the
-//     ds_read_b128 fragment reads conflict-free is applied on the SOURCE address (the LDS image of
-//     a DMA piece is lane-linear).  Two 64-KiB LDS buffers (K-tile parity), refilled slot by slot
-//     two K-tiles ahead behind COUNTED s_waitcnt vmcnt -- the queue is never drained in the loop.
-//   * 8 waves = 2 groups (frames halves) x 4 (64-channel columns); wave tile = MR x 2 accumulators
-//     of 32x32 (MR = 2, 3 or 4 per tile: 128, 192 or 256 frames).  The two waves of a SIMD belong to
-//     different groups and run one barrier apart ("ping-pong"): while one issues its 16 MFMAs of a
-//     phase, the other reads its next fragments from LDS and issues its DMA pieces, then they swap.
-//     A phase = 2 accumulator rows x 2 columns x 4 k-steps; 2 phases per K-tile.
-//   * persistent: a block owns a contiguous range of 64-frame units of one 256-channel column and
-//     cuts it into tiles of 4, 3 or 2 units, as equal as possible (a partial round of fixed 256-row
-//     tiles would idle a quarter of the chip at B=256: 584 tiles over 256 CUs).
-//   * epilogues: frames in the accumulator's registers, the channel on the lane, and a lane's two accumulators
-//     hold ADJACENT channels (a row permutation of the packed weights, pack.hip); bias / scale / shift of those
-//     two channels are 8-byte reads from a 3-KiB LDS table.  Store variant: ReLU + folded BatchNorm, v_cvt_pk_bf16_f32 joins the two
-//     columns and a store instruction writes two whole 128-byte row segments.  Pooling variant (layer 5): pivoted
-//     sums (K, sum (r-K), sum (r-K)^2) of r = relu(z + bias) per (32-frame group, utterance), 8-byte pairs per lane.
+// Why a second mapping.  The 128x128-tile kernel of tdnn_layer.hip moves 512 B from L2 per 32x32x16-equivalent MFMA; at the
+// bf16 rate that is ~52 B/clk per CU against the ~64 B/clk the L2 -> CU path delivers, so loads and MFMAs add up instead of
+// overlapping.  Here:
+//   * ONE 512-thread block per CU, tile = up to 256 frames x 256 channels, K in 64-wide tiles (128-byte rows): half the L2
+//     traffic per MFMA.
+//   * both operands go global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds: no staging registers, no ds_write), 1-KiB pieces
+//     of 8 rows x 128 B; the 16-byte-chunk XOR swizzle (row >> 1) & 7 that makes the ds_read_b128 fragment reads conflict-free
+//     is applied on the SOURCE address (the LDS image of a DMA piece is lane-linear).  Two 64-KiB LDS buffers (K-tile parity),
+//     refilled slot by slot two K-tiles ahead behind COUNTED s_waitcnt vmcnt -- the queue is never drained in the loop.
+//   * 8 waves = 2 groups (frames halves) x 4 (64-channel columns); wave tile = MR x 32 frames x 64 channels (MR = 2, 3 or 4 per
+//     tile: 128, 192 or 256 frames), per 32-frame acc row 2 frame blocks x 4 channel blocks of 16x16 (4 registers each: frame
+//     4 q + e of the block on lane quad q = l >> 4, channel c = l & 15 of the channel block).  Fragments: lane (c, q) reads row
+//     16 fb + c of a 32-row block, 16-byte chunk 4 s + q of k-step s (two k-steps of 32 per K-tile).  The two waves of a SIMD
+//     belong to different groups and run one barrier apart ("ping-pong"): while one issues the MFMAs of a segment, the other
+//     reads its next fragments from LDS and issues its DMA pieces, then they swap.  Two MFMA segments per K-tile.
+//   * persistent: a block owns a contiguous range of 64-frame units of one 256-channel column and cuts it into tiles of 4, 3 or
+//     2 units, as equal as possible (a partial round of fixed 256-row tiles would idle a quarter of the chip at B = 256).
+//   * weights: row 16 cb + c of a wave's 64-channel block holds channel 4 c + cb (pack.hip), so a lane's four accumulators of a
+//     frame hold four ADJACENT channels: the store epilogue writes 8 bytes per lane = whole 128-byte row segments of four frames
+//     per instruction.
+//   * epilogues (they run in the open: both waves of a SIMD are in theirs together).  Plain bf16 stores relu(z + bias') only --
+//     the bias is in the accumulators (srcC of a tile's first MFMAs), the BatchNorm is deferred into the consumer's weights
+//     (xvec_api.hip, refold), the ReLU is taken on the packed pair (relu_pk_bf16).  Layer 5 (POOL) emits pooling partials per
+//     (block, utterance, frames half) instead of its [frames, 1500] output: plain bf16 forms the sums on the MATRIX pipe
+//     (SegMx below), bf16x3 on the vector pipe at fp32 (Seg / pool_rows).  bf16x3 applies bias, ReLU and BatchNorm itself and
+//     writes the hi and lo planes.
 // The next tile's first K-tiles are requested before the epilogue, so the DMA flies under it.
 #include "tdnn_common.h"
 
@@ -496,13 +480,12 @@ constexpr int kBlk16 = 16 * kRowB;                // 16 rows of a 32-row block: 
         ++wq;                                                                       \
     }
 
-// Fused statistics pooling for the pooling variant (main.py:59-63), frames in the accumulator registers and
-// the channel on the lane.  The epilogue runs in the open here (both waves of a SIMD are in it at the same
-// time, the matrix pipe idles), so it is as short as the arithmetic allows: per (32-frame group, utterance)
-// and channel the pivoted sums S1 = sum (r - K), S2 = sum (r - K)^2 of r = relu(z + bias) over the utterance's
-// frames in the group, K = the group's frame 0 (tdnn_common.h, pool_group_impl: why a pivot) -- one v_max, half a
-// v_pk_add for the pivot, half a v_pk_add and half a v_pk_fma per value.  Scale and shift of the folded BatchNorm
-// are applied by pool_finalize.
+// Fused statistics pooling of the pooling variant (main.py:59-63), VECTOR-pipe form (bf16x3; plain bf16 uses the matrix-pipe
+// form, SegMx below): frames in the accumulator registers, the channel on the lane.  The epilogue runs in the open here (both
+// waves of a SIMD are in it at the same time, the matrix pipe idles): per (segment of an utterance, channel) the pivoted sums
+// S1 = sum (r - K), S2 = sum (r - K)^2 of r = relu(z + bias), K = frame 0 of the group in which the segment's first rows fall
+// (tdnn_common.h, pool_group_impl: why a pivot) -- one v_max, one v_sub, one v_add and one v_fma per value.  Scale and shift of
+// the folded BatchNorm are applied by pool_finalize.
 // RAGGED is a template parameter and the utterance index is kept provably wave-uniform on purpose: with
 // a run-time "offsets ? load : multiply" hipcc emitted VECTOR loads of the offsets followed by
 // s_waitcnt vmcnt(0) -- on the fixed-length path too -- and every one of those waits drained the DMA
@@ -556,8 +539,7 @@ __device__ __forceinline__ float quad0(float x) {
 // of its CURRENT utterance -- pivot K, S1 = sum (r - K), S2 = sum (r - K)^2 per lane and channel, r = relu(z + bias) --
 // across tiles (parked in LDS during the K loops: the loop has no register to spare) and writes ONE partial per
 // (block, group, utterance): 2 x (blocks per column + utterances) slots instead of one per 32-frame group (47 MB ->
-// 11 MB at the bench batch), no cross-lane traffic and no store in the common case: per value one v_max and half a
-// v_pk_add (pivot), v_pk_add, v_pk_fma.  Layout of a slot: tdnn_common.h's three planes K | S1 | S2 of n_pad floats;
+// 11 MB at the bench batch), no cross-lane traffic and no store in the common case.  Layout of a slot: tdnn_common.h's three planes K | S1 | S2 of n_pad floats;
 // slot of (block b of the column, utterance u, group g) = 2 (b + u) + g -- b and u both grow along the rows, so
 // consecutive segments get distinct slots -- and the number of frames behind a partial goes to pool_cnt[slot]
 // (pool_finalize_seg needs it to re-base the pivots).  Every wave writes a partial, possibly of zero frames, for EVERY

@@ -3,8 +3,8 @@
 The end-to-end x-vector checks average ~286 frames per output value and were shown blind to sparse row
 corruption (a WAR race and a 128-bit-store hazard both passed them), so here every ELEMENT of every layer's
 output is compared at sizes that dispatch
-  * `pp::tdnn_pp_kernel<false>` (tdnn_pp.hip, store variant: layers 2-4, and layer 5 through the per-layer entry),
-  * `pp::tdnn_pp_kernel<true>` (layer 5 + fused pooling, through `xvec_tdnn_pool_layer`),
+  * `pp16::tdnn_pp_kernel<false, X3>` (tdnn_pp16.hip, store variant: layers 2-4, and layer 5 through the per-layer entry),
+  * `pp16::tdnn_pp_kernel<true, X3>` (layer 5 + fused pooling, through `xvec_tdnn_pool_layer`),
   * `first::tdnn_first_kernel` (tdnn_first.hip, layer 1 reading fp32 rows),
 with every tile height the persistent blocks cut: 52 utterances of 300 frames (the smallest batch that dispatches them:
 1.8 units of 64 frames per CU) give blocks of 1 or 2 units (a 2-unit tile whose second unit is masked), 63 blocks of 2 or 3 units,

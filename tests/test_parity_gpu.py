@@ -506,3 +506,66 @@ def test_bf16_mid_size_batches(sd42, synth, gpu_model, B, T):
     lens = np.random.default_rng(B).integers(T // 2, T + 1, B)
     outr = m.extract_x_vec(x, lengths=lens.tolist())
     assert_parity(outr, gpu_model.extract_x_vec(x, lengths=lens.tolist()), 1e-2, "ragged vs fp32", elem_tol=2e-2)
+
+
+# ------------------------------------------------------------------ plain bf16: BatchNorm deferred into the consumer
+@pytest.mark.gpu
+def test_bf16_deferred_batchnorm_signs_zeros_and_load_order(sd42, synth):
+    """Plain bf16 keeps ReLU outputs between layers and folds each layer's eval BatchNorm (tdnn_layer.py:36-39) into the NEXT
+    layer's weights and bias (xvec_api.hip, refold).  The fold must hold for any BatchNorm a checkpoint can carry -- negative
+    and exactly-zero gamma, large running means -- and for any order in which the C ABI is given the layers."""
+    import ctypes as C
+    import xvector_amd as xa
+    import xvector_oracle as oracle
+    from conftest import float_params
+    from xvector_amd import hip as _hip
+    sd = {k: v.clone() for k, v in sd42.items()}
+    g = torch.Generator().manual_seed(7)
+    for i in range(5):
+        w = sd[f"time_context_layers.{i}.norm.weight"]
+        sign = torch.where(torch.rand(w.shape, generator=g) < 0.3, -1.0, 1.0)
+        w.mul_(sign)
+        w[torch.rand(w.shape, generator=g) < 0.02] = 0.0                       # channels switched off by gamma = 0
+        sd[f"time_context_layers.{i}.norm.running_mean"].add_(2.0 * torch.randn(w.shape, generator=g))
+    x = torch.as_tensor(synth.make_mfcc(96, 300, seed=71))
+    p64 = oracle.cast_params(float_params(sd), torch.float64)
+    idx = [0, 1, 47, 95]
+    ref = oracle.extract_x_vec(x[idx].double(), p64)
+    ref_pooled = oracle.stat_pool(oracle.time_context_layers(x[idx].double(), p64))
+    m = xa.XVectorModel(precision="bf16")
+    m.load_state_dict(sd)
+    m = m.to(DEV).eval()
+    got = m.extract_x_vec(x.to(DEV))
+    assert m.last_dispatch() == ["first", "pp", "pp", "pp", "pp"]
+    assert_parity(got[idx], ref, 1e-2, "bf16 x-vectors, BatchNorm with negative / zero gamma")
+    assert_parity(m.pooled(x.to(DEV))[idx], ref_pooled, 1e-2, "bf16 pooled statistics, BatchNorm with negative / zero gamma")
+    # the per-layer entry takes and returns the reference's tensors (BatchNorm applied on both sides)
+    h = oracle.tdnn_layer(x[:8].double(), p64, "time_context_layers.0.", oracle.CONTEXTS[0])
+    h2 = oracle.tdnn_layer(h, p64, "time_context_layers.1.", oracle.CONTEXTS[1])
+    assert_parity(m.time_context_layers[1](h.float().to(DEV)), h2, 1e-2, "bf16 layer 2 alone, zero-gamma input channels", elem_tol=4e-2)
+    # the same weights handed to a second handle in REVERSE layer order: every layer's bf16 copies depend on its producer's
+    # BatchNorm, whichever of the two arrives first
+    eng = m._engine(torch.device(DEV))
+    h2nd = C.c_void_p()
+    _hip.check(_hip.lib.xvec_create(C.byref(eng.cfg), C.byref(h2nd)))
+    try:
+        keep = []
+        for i in reversed(range(5)):
+            layer = m.time_context_layers[i]
+            ts = [t.detach().contiguous() for t in (layer.linear.weight, layer.linear.bias, layer.norm.weight, layer.norm.bias,
+                                                    layer.norm.running_mean, layer.norm.running_var)]
+            keep += ts
+            _hip.check(_hip.lib.xvec_load_tdnn(h2nd, i, *[t.data_ptr() for t in ts], layer.norm.eps, None))
+        for which, lin in ((_hip.SEG6, m.segment_layer6), (_hip.SEG7, m.segment_layer7), (_hip.OUTPUT, m.output)):
+            _hip.check(_hip.lib.xvec_load_affine(h2nd, which, lin.weight.data_ptr(), lin.bias.data_ptr(), None))
+        torch.cuda.synchronize()
+        xd = x.to(DEV).contiguous()
+        n = _hip.lib.xvec_workspace_bytes(h2nd, 96 * 300, 96)
+        ws = torch.empty(int(n), dtype=torch.uint8, device=DEV)
+        out = torch.empty((96, 512), dtype=torch.float32, device=DEV)
+        _hip.check(_hip.lib.xvec_forward(h2nd, xd.data_ptr(), None, 96, 300, _hip.MODE_XVEC6, _hip.BF16, out.data_ptr(),
+                                         ws.data_ptr(), ws.numel(), None))
+        torch.cuda.synchronize()
+        assert torch.equal(out, got), "layers loaded in reverse order give other x-vectors"
+    finally:
+        _hip.lib.xvec_destroy(h2nd)

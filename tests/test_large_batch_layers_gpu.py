@@ -147,7 +147,8 @@ def test_bf16_fused_pooling_layer(gpu_model, sd42, synth, models, B, T):
     # zero: they carry the bf16 rounding of layer 4's output at 5-10 % of their tiny std, in the fp32 reference's own
     # bf16-rounded run too), which are LISTED (at most 0.1 % of the elements), not covered by a wide tolerance
     off = nearly_off_channels(_pre_bn(frames, sd42, 4), ref[:, 1500:])
-    assert_parity_masked(got[idx][:, 1500:], ref[:, 1500:], 1e-2, f"std half alone B={B} T={T}", 2e-2, off)
+    assert_parity_masked(got[idx][:, 1500:], ref[:, 1500:], 1e-2, f"std half alone B={B} T={T}", 2e-2, off,
+                         atol_scale=ref.abs().mean().item())
     # the fp32 kernel's fused pooling on the same input, every utterance
     assert_parity(got, gpu_model.pooled_last_layer(h), 1e-2, "vs fp32 fused pooling")
 
@@ -323,6 +324,8 @@ def test_fp32_every_layer_every_element_at_the_bench_size(gpu_model, sd42, synth
             ref = oracle.stat_pool(frames)
             assert_parity(pooled[:, :1500], ref[:, :1500], 1e-4, "fp32 pooled means, B=256")
             # stds at the path's own bar element by element; the nearly-off channels (one of 384 000 sat at 1.x e-4) are listed
-            off = nearly_off_channels(_pre_bn(frames, sd42, 4), ref[:, 1500:])
-            assert_parity_masked(pooled[:, 1500:], ref[:, 1500:], 1e-4, "fp32 pooled stds, B=256", 1e-4, off)
+            pre = got.cpu().double() @ p64["time_context_layers.4.linear.weight"].T + p64["time_context_layers.4.linear.bias"]
+            off = nearly_off_channels(_pre_bn(frames, sd42, 4), ref[:, 1500:], pre)
+            assert_parity_masked(pooled[:, 1500:], ref[:, 1500:], 1e-4, "fp32 pooled stds, B=256", 1e-4, off,
+                                 atol_scale=ref.abs().mean().item())
         h = got

@@ -8,6 +8,7 @@ out = {}
 for arg in sys.argv[1:]:
     name, root = arg.split("=", 1)
     with tempfile.NamedTemporaryFile(suffix=".json") as f:
-        subprocess.run([sys.executable, os.path.join(here, "summarize_pmc.py"), root, f.name], check=True, stdout=subprocess.DEVNULL)
+        what = "profiles/diag/next_rows_pmc.py" if name == "next_rows" else "bench.py --steps 3 --warmup 1"
+        subprocess.run([sys.executable, os.path.join(here, "summarize_pmc.py"), root, f.name, what], check=True, stdout=subprocess.DEVNULL)
         out[name] = json.load(open(f.name))
 json.dump(out, sys.stdout, indent=1)

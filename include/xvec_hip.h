@@ -47,8 +47,9 @@ enum {
     XVEC_ERR_TOO_LARGE = 5 /* the batch exceeds one of the per-call size limits below: the same data in several smaller calls works */
 };
 
-/* arithmetic of the frame-level stack (accumulation, pooling and the segment-level
- * affines are fp32 in both) */
+/* arithmetic of the frame-level stack (accumulation and pooling are fp32 in all three; the segment-level affines
+ * are fp32 MFMAs in XVEC_F32 and XVEC_BF16X3, and bf16x3 products -- fp32 operands as bf16 pairs, 6e-6 of fp64 -- in
+ * XVEC_BF16) */
 enum {
     XVEC_F32 = 0,   /* exact fp32 on v_mfma_f32_32x32x2_f32 (the reference's arithmetic) */
     XVEC_BF16 = 1,  /* bf16 activations and weights (parity bar 1e-2).  Between layers this mode keeps the ReLU outputs (bf16) and

@@ -8,6 +8,7 @@
 // Operands are read once per block straight into registers (16 B per lane, 64 contiguous bytes per
 // row and instruction); they are small enough to stay in L2.
 #include "xvec_internal.h"
+#include "tdnn_common.h"
 #include <algorithm>
 
 namespace xvec {
@@ -181,16 +182,172 @@ __global__ __launch_bounds__(256, 2) void affine_splitk_kernel(const float* __re
 #undef AFS_LOAD
     // accumulator element e of lane (i, kh): row = (e&3) + 8*(e>>2) + 4*kh, col = i
     const int m0 = bm0 + 32 * (wave >> 1), col = bn0 + 32 * (wave & 1) + i;
-    if (col >= N) return;
-    float* dst = DIRECT ? out : out + (int64_t)split * M * N;
-    const float bias = DIRECT ? b[col] : 0.f;
+    if (col < N) {
+        float* dst = DIRECT ? out : out + (int64_t)split * M * N;
+        const float bias = DIRECT ? b[col] : 0.f;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        const int row = m0 + (e & 3) + 8 * (e >> 2) + 4 * kh;
-        if (row < M) {
-            float v = acc0[e] + acc1[e] + bias;
-            if (DIRECT && relu) v = fmaxf(v, 0.f);
-            dst[(int64_t)row * N + col] = v;
+        for (int e = 0; e < 16; ++e) {
+            const int row = m0 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+            if (row < M) {
+                float v = acc0[e] + acc1[e] + bias;
+                if (DIRECT && relu) v = fmaxf(v, 0.f);
+                dst[(int64_t)row * N + col] = v;
+            }
+        }
+    }
+}
+
+// ---- round 4: bf16x3 arithmetic for the segment layers of XVEC_BF16 ------------------------------------------------
+// XVEC_BF16 runs the frame-level stack at bf16 matrix rates and then spent 13 us in the fp32 split-K GEMM above, 5 of
+// them MFMA time (v_mfma_f32_32x32x2_f32: 256 flop per cycle and CU; measured by knocking 7/8 of the MFMAs out).
+// Here every fp32 operand is two bf16 (hi = bf16(v), lo = bf16(v - hi)) and a product is x_lo*W_hi + x_hi*W_lo +
+// x_hi*W_hi on v_mfma_f32_16x16x32_bf16, as the frame-level layers of XVEC_BF16X3 (every product exact in the fp32
+// accumulator, what is dropped is 2^-16 relative: 6e-6 of the fp64 result, test_segment_layers_inside_the_path;
+// XVEC_BF16X3, which promises the fp32 bar end to end, keeps the fp32 kernel).  W comes pre-split
+// (split_pairs_kernel: the 16 bytes of four consecutive k hold hi01 hi23 lo01 lo23, so the row stride and the
+// 256-byte coalesced staging loads are those of the fp32 matrix); x is split while it is staged.  LDS: four planes
+// (x hi, x lo, W hi, W lo) of 64 rows x 64 k bf16, 16-byte chunk c of row r at chunk c ^ (r & 7): the fragment reads
+// (ds_read_b128) and the staging writes (8 bytes per plane) are conflict-free by the guide's lane-group rules
+// (simulated, every access).  13.2 -> 10.5 us; the second kernel stays.  (Tried and dropped: the tile's last block
+// adding the K ranges up itself -- its ranges sit behind eight different L2s, and the agent-scope fences that make
+// the partials visible, buffer_wbl2 sc1 / buffer_inv sc1, walk the whole L2 once per block: 75 us.)
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {
+    const f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+
+// W[N][K] fp32 -> the same [N][K] dwords, every four consecutive k as hi01 | hi23 | lo01 | lo23 (K % 4 == 0)
+__global__ __launch_bounds__(256) void split_pairs_kernel(const float4* __restrict__ W, uint4* __restrict__ out, int64_t n4) {
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (q >= n4) return;
+    const float4 v = W[q];
+    uint4 o;
+    o.x = pk_bf16(v.x, v.y);
+    o.y = pk_bf16(v.z, v.w);
+    o.z = pk_bf16(v.x - __uint_as_float(o.x << 16), v.y - __uint_as_float(o.x & 0xffff0000u));
+    o.w = pk_bf16(v.z - __uint_as_float(o.y << 16), v.w - __uint_as_float(o.y & 0xffff0000u));
+    out[q] = o;
+}
+
+hipError_t launch_split_pairs(const float* W, void* out, int64_t n, hipStream_t s) {
+    if (n <= 0 || (n & 3)) return hipErrorInvalidValue;
+    const int64_t n4 = n / 4;
+    split_pairs_kernel<<<(unsigned)((n4 + 255) / 256), 256, 0, s>>>(reinterpret_cast<const float4*>(W),
+                                                                     static_cast<uint4*>(out), n4);
+    return hipGetLastError();
+}
+
+constexpr int kAx3Plane = 64 * 128;                // bytes: 64 rows x 64 bf16
+
+__global__ __launch_bounds__(256, 2) void affine_splitk_x3_kernel(const float* __restrict__ x, const uint4* __restrict__ W3,
+                                                                  const float* __restrict__ b, float* __restrict__ out, int M,
+                                                                  int N, int K, int relu, int trips_per_split, int tn,
+                                                                  int tiles, int S) {
+    __shared__ __attribute__((aligned(16))) char lds[4 * kAx3Plane];     // x hi | x lo | W hi | W lo
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, kq = lane >> 4;
+    int split = 0, tile = blockIdx.x;
+    if (S > 1) {                                    // K ranges dealt to the XCDs: see affine_splitk_kernel
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        split = xcd + 8 * (idx / tiles);
+        tile = idx % tiles;
+        if (split >= S) return;
+    }
+    const int bm0 = (tile / tn) * 64, bn0 = (tile % tn) * 64;
+    const int trips = (K + 63) / 64;
+    const int t_lo = split * trips_per_split, t_hi = min(trips, t_lo + trips_per_split);
+    const int K4 = K >> 2;
+
+    // staging map: 16 lanes per row (the trip's 64 k), 16 rows per pass, 4 passes per operand
+    const int s_row = tid >> 4, q = tid & 15;
+    const float* xs[4];
+    const uint4* ws[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {                // clamped rows: results discarded
+        xs[p] = x + (int64_t)min(bm0 + s_row + 16 * p, M - 1) * K;
+        ws[p] = W3 + (int64_t)min(bn0 + s_row + 16 * p, N - 1) * K4;
+    }
+    const int st_off = s_row * 128 + (((q >> 1) ^ (s_row & 7)) << 4) + ((q & 1) << 3);     // + 16 * p rows
+    float4 ra0[4], ra1[4];        // two register sets, as affine_splitk_kernel (a third measured the same)
+    uint4 rb0[4], rb1[4];
+#define AX3_LOAD(S_, t_)                                                                              \
+    _Pragma("unroll") for (int p = 0; p < 4; ++p) {                                                   \
+        const int k = 64 * (t_) + 4 * q;                                                              \
+        ra##S_[p] = ld4<true>(xs[p], k, K);                                                           \
+        rb##S_[p] = (k < K) ? ws[p][k >> 2] : make_uint4(0u, 0u, 0u, 0u);                             \
+    }
+    f32x4v acc[2][2];
+#pragma unroll
+    for (int r_ = 0; r_ < 2; ++r_)
+#pragma unroll
+        for (int c_ = 0; c_ < 2; ++c_) acc[r_][c_] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    // fragment reads: lane (i, kq) holds k = 32s + 8kq .. +7 of row i of a 16-row block
+    const int fa = (32 * (wave >> 1) + i) * 128, fb = 2 * kAx3Plane + (32 * (wave & 1) + i) * 128;
+    const int sw = i & 7;
+#define AX3_TRIP(S_, t_)                                                                              \
+    {                                                                                                 \
+        __syncthreads(); /* the previous trip's fragment reads are done */                            \
+        _Pragma("unroll") for (int p = 0; p < 4; ++p) {                                               \
+            const float4 v = ra##S_[p];                                                               \
+            uint2 hi, lo;                                                                             \
+            hi.x = pk_bf16(v.x, v.y);                                                                 \
+            hi.y = pk_bf16(v.z, v.w);                                                                 \
+            lo.x = pk_bf16(v.x - __uint_as_float(hi.x << 16), v.y - __uint_as_float(hi.x & 0xffff0000u)); \
+            lo.y = pk_bf16(v.z - __uint_as_float(hi.y << 16), v.w - __uint_as_float(hi.y & 0xffff0000u)); \
+            char* d = lds + st_off + 16 * p * 128;                                                    \
+            *reinterpret_cast<uint2*>(d) = hi;                                                        \
+            *reinterpret_cast<uint2*>(d + kAx3Plane) = lo;                                            \
+            *reinterpret_cast<uint2*>(d + 2 * kAx3Plane) = make_uint2(rb##S_[p].x, rb##S_[p].y);      \
+            *reinterpret_cast<uint2*>(d + 3 * kAx3Plane) = make_uint2(rb##S_[p].z, rb##S_[p].w);      \
+        }                                                                                             \
+        __syncthreads();                                                                              \
+        if ((t_) + 2 < t_hi) AX3_LOAD(S_, (t_) + 2)                                                   \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                            \
+            const int co = ((4 * ks + kq) ^ sw) << 4;                                                 \
+            bf16x8 ah[2], al[2], bh[2], bl[2];                                                        \
+            _Pragma("unroll") for (int r_ = 0; r_ < 2; ++r_) {                                        \
+                ah[r_] = *reinterpret_cast<const bf16x8*>(lds + fa + r_ * 16 * 128 + co);             \
+                al[r_] = *reinterpret_cast<const bf16x8*>(lds + kAx3Plane + fa + r_ * 16 * 128 + co); \
+                bh[r_] = *reinterpret_cast<const bf16x8*>(lds + fb + r_ * 16 * 128 + co);             \
+                bl[r_] = *reinterpret_cast<const bf16x8*>(lds + kAx3Plane + fb + r_ * 16 * 128 + co); \
+            }                                                                                         \
+            _Pragma("unroll") for (int r_ = 0; r_ < 2; ++r_)                                          \
+                _Pragma("unroll") for (int c_ = 0; c_ < 2; ++c_) {                                    \
+                    acc[r_][c_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[r_], bh[c_], acc[r_][c_], 0, 0, 0); \
+                    acc[r_][c_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[r_], bl[c_], acc[r_][c_], 0, 0, 0); \
+                }                                                                                     \
+            _Pragma("unroll") for (int r_ = 0; r_ < 2; ++r_)                                          \
+                _Pragma("unroll") for (int c_ = 0; c_ < 2; ++c_)                                      \
+                    acc[r_][c_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[r_], bh[c_], acc[r_][c_], 0, 0, 0); \
+        }                                                                                             \
+    }
+    if (t_lo < t_hi) AX3_LOAD(0, t_lo)
+    if (t_lo + 1 < t_hi) AX3_LOAD(1, t_lo + 1)
+    for (int t = t_lo; t < t_hi; t += 2) {
+        AX3_TRIP(0, t)
+        if (t + 1 < t_hi) AX3_TRIP(1, t + 1)
+    }
+#undef AX3_TRIP
+#undef AX3_LOAD
+    // accumulator element e of lane (i, kq) of block (r_, c_): row = 16 r_ + 4 kq + e, col = 16 c_ + i
+    const bool direct = S == 1;
+    float* dst = direct ? out : out + (int64_t)split * M * N;
+#pragma unroll
+    for (int c_ = 0; c_ < 2; ++c_) {
+        const int col = bn0 + 32 * (wave & 1) + 16 * c_ + i;
+        if (col < N) {
+            const float bias = direct ? b[col] : 0.f;
+#pragma unroll
+            for (int r_ = 0; r_ < 2; ++r_)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int row = bm0 + 32 * (wave >> 1) + 16 * r_ + 4 * kq + e;
+                    if (row < M) {
+                        float v = acc[r_][c_][e] + bias;
+                        if (direct && relu) v = fmaxf(v, 0.f);
+                        dst[(int64_t)row * N + col] = v;
+                    }
+                }
         }
     }
 }
@@ -221,7 +378,7 @@ __global__ __launch_bounds__(256) void affine_reduce_kernel(const float* __restr
 }
 
 hipError_t launch_affine_f32(const float* x, const float* W, const float* b, float* y, int M, int N,
-                             int K, int relu, hipStream_t s, float* scratch, size_t scratch_bytes) {
+                             int K, int relu, hipStream_t s, float* scratch, size_t scratch_bytes, const void* W3) {
     if (M <= 0 || N <= 0) return hipSuccess;
     const bool vec16 = (K % 4 == 0) && (((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(W)) & 15) == 0);
     const int64_t MN = (int64_t)M * N;
@@ -230,16 +387,24 @@ hipError_t launch_affine_f32(const float* x, const float* W, const float* b, flo
         int S = (512 + tm * tn - 1) / (tm * tn);                     // about two blocks per CU
         S = std::min(S, std::max(trips / 2, 1));                     // at least two trips per range
         S = (int)std::min<int64_t>(std::min(S, 16), (int64_t)(scratch_bytes / 4) / MN);
+        const uint4* w3 = static_cast<const uint4*>(W3);      // bf16x3 form: see affine_splitk_x3_kernel
         if (S <= 1 && tm * tn >= 256) {
-            affine_splitk_kernel<true><<<dim3(tn * tm), 256, 0, s>>>(x, W, b, y, M, N, K, relu, trips, tn, tn * tm, 1);
+            if (w3)
+                affine_splitk_x3_kernel<<<dim3(tn * tm), 256, 0, s>>>(x, w3, b, y, M, N, K, relu, trips, tn, tn * tm, 1);
+            else
+                affine_splitk_kernel<true><<<dim3(tn * tm), 256, 0, s>>>(x, W, b, y, M, N, K, relu, trips, tn, tn * tm, 1);
             return hipGetLastError();
         }
         if (S > 1) {
             const int tps = (trips + S - 1) / S;
             S = (trips + tps - 1) / tps;
             const int s_pad = (S + 7) & ~7;                       // ranges s_pad-S..: blocks that exit at once
-            affine_splitk_kernel<false><<<dim3(s_pad * tn * tm), 256, 0, s>>>(x, W, b, scratch, M, N, K, relu, tps, tn,
+            if (w3)
+                affine_splitk_x3_kernel<<<dim3(s_pad * tn * tm), 256, 0, s>>>(x, w3, b, scratch, M, N, K, relu, tps, tn,
                                                                                tn * tm, S);
+            else
+                affine_splitk_kernel<false><<<dim3(s_pad * tn * tm), 256, 0, s>>>(x, W, b, scratch, M, N, K, relu, tps, tn,
+                                                                                   tn * tm, S);
             affine_reduce_kernel<<<(unsigned)((MN / 4 + 255) / 256), 256, 0, s>>>(scratch, b, y, MN, N, S, relu);
             return hipGetLastError();
         }

@@ -48,7 +48,7 @@ namespace xvec {
 
 constexpr int kBM = 128, kBN = 128;
 constexpr int kStageFloats = (kBM + kBN) * kBK;   // one LDS buffer: A tile then B tile
-constexpr int kConstFloats = 3 * kBN;             // bias | scale | shift of the block's 128 channels (epilogue)
+constexpr int kConstFloats = 3 * kBN;             // bias | scale | shift of the block's 128 channels (pooling: bias | bias - K | -K)
 constexpr int kLdsBytes = (2 * kStageFloats + kConstFloats) * 4;
 
 #ifdef XVEC_DIAG
@@ -75,6 +75,7 @@ struct Ctx {
     int64_t m0;          // first flat row of the tile the load stream is in
     int64_t g_s, g_end;  // that tile's first row group; end of this block's row range
     PoolCur pool;        // compute side: pooling cursor (POOL variants)
+    bool pivot_set;      // POOL: the block's pooling pivots are in LDS (false until its first tile's epilogue)
     int tap, kc, itl;    // next chunk to fetch: (tap, kc) and its linear index within the tile
     int es;              // bytes per input element (4: fp32, 2: bf16)
 };
@@ -452,6 +453,14 @@ __device__ __forceinline__ void process_tile(const TdnnArgs& a, float* smem, Ctx
             acc0[4 * gq] = b4.x; acc0[4 * gq + 1] = b4.y; acc0[4 * gq + 2] = b4.z; acc0[4 * gq + 3] = b4.w;
         }
         acc1 = acc0; acc2 = acc0; acc3 = acc0;
+    } else if constexpr (POOL) {
+        // accumulators start at bias - K, K = the block's pooling pivot of this lane's channel (at 0 in the block's
+        // first tile, whose epilogue picks K and adds bias - K: a large bias must not sit in the accumulator while
+        // the K loop adds small terms to it -- every MFMA would round at ulp(bias)): tdnn_common.h, pool_group_impl
+        const float b0 = smem[2 * kStageFloats + kBN + (ln.col - n0)];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc0[e] = b0;
+        acc1 = acc0; acc2 = acc0; acc3 = acc0;
     } else {
 #pragma unroll
         for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; acc2[e] = 0.f; acc3[e] = 0.f; }
@@ -484,8 +493,27 @@ __device__ __forceinline__ void process_tile(const TdnnArgs& a, float* smem, Ctx
     const int col = ln.col;
     // epilogue constants of this lane's channel: three LDS reads per tile instead of three registers held
     // across the K loop (the pooling and first-layer variants were 3-6 registers over the 256 budget)
-    const float* cst = smem + 2 * kStageFloats + (col - n0);
+    float* cst = smem + 2 * kStageFloats + (col - n0);
     const float bi = cst[0], sc = cst[kBN], sh = cst[2 * kBN];
+    // pooling variants: the three slots are bias | bias - K | -K (this wave's own channels: no barrier)
+    float negk = sh;
+    if constexpr (POOL) {
+        if (!cx.pivot_set) {       // block-uniform: the block's first tile, whose accumulators started at 0
+            const float piv = lower_half(fmaxf(acc0[0] + bi, 0.f));     // r of the block's first frame
+            const float bmk = bi - piv;
+            negk = bmk - bi;                                      // minus the pivot the tiles really carry
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                acc0[e] += bmk;
+                if constexpr (G > 1) acc1[e] += bmk;
+                if constexpr (G > 2) acc2[e] += bmk;
+                if constexpr (G > 3) acc3[e] += bmk;
+            }
+            cst[kBN] = bmk;
+            cst[2 * kBN] = negk;
+            cx.pivot_set = true;
+        }
+    }
     // Two phases per row group: (1) all 16 values finished IN PLACE in the accumulator registers,
     // (2) 16 stores issued back to back from those 16 distinct registers, addressed by a per-tile
     // buffer descriptor + one per-lane offset + a scalar row offset.  (Computing each value into a
@@ -503,10 +531,13 @@ __device__ __forceinline__ void process_tile(const TdnnArgs& a, float* smem, Ctx
     }
 #define XV_EPI(i_)                                                                                        \
     if constexpr (G > i_) {                                                                               \
-        /* pooling variant: r = relu(z + bias) only; scale / shift are applied by pool_finalize */         \
-        _Pragma("unroll") for (int e = 0; e < 16; ++e)                                                    \
-            acc##i_[e] = POOL ? fmaxf(acc##i_[e] + bi, 0.f) : fmaf(fmaxf(acc##i_[e] + bi, 0.f), sc, sh);  \
-        asm volatile("" : "+v"(acc##i_));                                                                 \
+        /* pooling variant: the accumulator holds z + bias - K; ReLU and sums in pool_group, BatchNorm in  \
+           pool_finalize */                                                                               \
+        if constexpr (!POOL) {                                                                            \
+            _Pragma("unroll") for (int e = 0; e < 16; ++e)                                                \
+                acc##i_[e] = fmaf(fmaxf(acc##i_[e] + bi, 0.f), sc, sh);                                   \
+            asm volatile("" : "+v"(acc##i_));                                                             \
+        }                                                                                                 \
         if (STORE) {                                                                                      \
             _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                              \
                 const int soff = (i_ * 32 + (e & 3) + 8 * (e >> 2)) * a.ldy * esz;                        \
@@ -525,7 +556,7 @@ __device__ __forceinline__ void process_tile(const TdnnArgs& a, float* smem, Ctx
                 }                                                                                         \
             }                                                                                             \
         }                                                                                                 \
-        if (POOL) pool_group(a, acc##i_, m0 + i_ * 32, h, col, cx.pool);                                   \
+        if (POOL) pool_group(a, acc##i_, negk, m0 + i_ * 32, h, col, cx.pool);                            \
     }
     if constexpr (SWAP) {
         float4 sc4[4], sh4[4];
@@ -609,8 +640,8 @@ __global__ __launch_bounds__(256, 2) void tdnn_kernel(const TdnnArgs a) {
     ln.col = n0 + wave * 32 + r;
     if (tid < kBN) {
         smem[2 * kStageFloats + tid] = a.bias[n0 + tid];
-        smem[2 * kStageFloats + kBN + tid] = a.scale[n0 + tid];
-        smem[2 * kStageFloats + 2 * kBN + tid] = a.shift[n0 + tid];
+        smem[2 * kStageFloats + kBN + tid] = POOL ? 0.f : a.scale[n0 + tid];
+        smem[2 * kStageFloats + 2 * kBN + tid] = POOL ? 0.f : a.shift[n0 + tid];
     }
 
     Ctx cx;
@@ -635,6 +666,7 @@ __global__ __launch_bounds__(256, 2) void tdnn_kernel(const TdnnArgs a) {
         cx.pool.u = cx.u_tile;
         cx.pool.end = cx.off_next;
     }
+    cx.pivot_set = false;
     set_tile_rows(a, cx);
     cx.tap = 0;
     cx.kc = 0;

@@ -170,9 +170,14 @@ struct PoolFinalizeArgs {
 hipError_t launch_pool_finalize(const PoolFinalizeArgs& a, hipStream_t s);
 
 // y[M,N] = act(x[M,K] . W[N,K]^T + b)   (PyTorch nn.Linear layout, fp32 MFMA).  With `scratch` (device memory the
-// call may overwrite) a small problem is split over K into scratch and reduced by a second kernel.
+// call may overwrite) a small problem is split over K into scratch and reduced by a second kernel.  With W3
+// (launch_split_pairs of W) the split form's products are bf16x3 instead of fp32 MFMAs: the segment layers of
+// XVEC_BF16.
 hipError_t launch_affine_f32(const float* x, const float* W, const float* b, float* y, int M, int N,
-                             int K, int relu, hipStream_t s, float* scratch = nullptr, size_t scratch_bytes = 0);
+                             int K, int relu, hipStream_t s, float* scratch = nullptr, size_t scratch_bytes = 0,
+                             const void* W3 = nullptr);
+// n floats (n % 4 == 0) -> n dwords: four consecutive values as bf16 pairs hi01 | hi23 | lo01 | lo23
+hipError_t launch_split_pairs(const float* W, void* out, int64_t n, hipStream_t s);
 
 // weight packing
 hipError_t launch_pack_tdnn(const float* W, const float* bias, const float* g, const float* be,

@@ -86,6 +86,33 @@ def test_affine_layers(gpu_model, sd42, M):
         assert_parity(gpu_model.affine(name, x.to(DEV), relu=True), torch.relu(ref), 1e-4, f"{name} relu M={M}")
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "bf16x3"])
+@pytest.mark.parametrize("B", [3, 37, 256])
+def test_segment_layers_inside_the_path(sd42, synth, precision, B):
+    """The segment-level layers as the forward path runs them (split over K into the dead activation buffers, the
+    ranges summed in order by a second kernel; bf16x3 products in plain bf16): from the SAME run's pooled
+    statistics, segment_layer6 / 7 / output in fp64 must agree at the fp32 bar in every precision -- the frame-level
+    arithmetic is out of the comparison.  The fixed summation order makes repeats bit-identical."""
+    import xvector_amd as xa
+    p64 = oracle.cast_params(float_params(sd42), torch.float64)
+    m = xa.XVectorModel(precision=precision)
+    m.load_state_dict(sd42)
+    m = m.to(DEV).eval()
+    x = _gpu(synth.make_mfcc(B, 150, seed=B))
+    pooled = m.pooled(x).double().cpu()
+    z6 = pooled @ p64["segment_layer6.weight"].t() + p64["segment_layer6.bias"]
+    z7 = torch.relu(z6) @ p64["segment_layer7.weight"].t() + p64["segment_layer7.bias"]
+    lg = torch.relu(z7) @ p64["output.weight"].t() + p64["output.bias"]
+    x6 = m.extract_x_vec(x)
+    assert_parity(x6, z6, 3e-5, f"{precision} segment_layer6 B={B}")
+    m.x_vec_extract_layer = 7
+    assert_parity(m.extract_x_vec(x), z7, 1e-4, f"{precision} segment_layer7 B={B}")
+    m.x_vec_extract_layer = 6
+    assert_parity(m.forward(x), lg, 1e-4, f"{precision} logits B={B}")
+    for _ in range(20):
+        assert torch.equal(m.extract_x_vec(x), x6), "repeat runs of the split-K reduction differ"
+
+
 # ------------------------------------------------------------------------------- whole path
 @pytest.mark.parametrize("B,T", [(1, 299), (8, 299), (1, 300), (8, 300)])
 def test_g4_full_path_vs_golden(sd42, synth, B, T):

@@ -11,6 +11,7 @@ for n in bf16 bf16x3 ragged ragged_bf16 job20k job20k_bf16 wave wave_bf16 collec
 done
 for dt in fp32 bf16 bf16x3; do
   cp $src/stats_$dt/${dt}_kernel_stats.csv profiles/${tag}_kernel_stats_$dt.csv
+  python3 profiles/summarize_trace.py $src/stats_$dt 20 > profiles/${tag}_timed_region_$dt.txt
 done
 cp $src/pmc_summary_fp32.txt profiles/${tag}_pmc_summary.txt
 cp $src/pmc_summary_bf16.txt profiles/${tag}_pmc_summary_bf16.txt

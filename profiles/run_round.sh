@@ -24,6 +24,7 @@ for dt in fp32 bf16 bf16x3; do
   mkdir -p $out/pmc_$dt
   [ -z "$ONLY_PMC" ] && rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_$dt -o $dt -- python3 bench.py --steps 20 --warmup 5 --cpu-budget 0 --no-secondary --dtype $dt > $out/stats_$dt.log 2>&1
   echo "stats $dt exit $?"
+  [ -z "$ONLY_PMC" ] && python3 profiles/summarize_trace.py $out/stats_$dt 20 > $out/timed_region_$dt.txt 2>&1
   i=0
   for grp in "FETCH_SIZE" "WRITE_SIZE" \
              "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" \

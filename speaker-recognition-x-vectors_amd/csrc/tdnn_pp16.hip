@@ -726,6 +726,15 @@ __device__ __forceinline__ unsigned cvt_pk(float x, float y) {
     return r;
 }
 
+// conversion and minimum as ONE statement: behind an asm statement whose result the next instruction reads hipcc puts an
+// s_nop 0 (it cannot know that the unknown instruction is not a transcendental one) -- sixteen per group, in an epilogue
+// whose vector issue slots both waves of the SIMD are queueing for
+__device__ __forceinline__ unsigned cvt_pk_min(float x, float y, unsigned m) {
+    unsigned r;
+    asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2\n\tv_pk_min_u16 %0, %0, %3" : "=&v"(r) : "v"(x), "v"(y), "v"(m));
+    return r;
+}
+
 // The pooling MFMAs are inline asm with the accumulator TIED, like the K loop's (PP_MF): with the builtin hipcc gave every
 // MFMA a fresh destination and copied the 32 accumulator registers at every merge of the bookkeeping's control flow -- 160
 // v_mov per 32-frame group next to 56 useful instructions (stamps: 1.4-2.0 k cycles per group, no better than the vector sums
@@ -813,8 +822,8 @@ __device__ __forceinline__ int rel_row(int64_t row, int64_t base) {
     u32x4 pk_ = ones_e;                                                                                        \
     if constexpr (!PP_KNOCK_MXPK) {                                                                            \
         const u32x4 m_ = MASKED_ ? mk & ncp[cb_] : u32x4{ncp[cb_], ncp[cb_], ncp[cb_], ncp[cb_]};             \
-        pk_ = u32x4{pk_min_u16(cvt_pk(v0_[0], v0_[1]), m_[0]), pk_min_u16(cvt_pk(v0_[2], v0_[3]), m_[1]),      \
-                    pk_min_u16(cvt_pk(v1_[0], v1_[1]), m_[2]), pk_min_u16(cvt_pk(v1_[2], v1_[3]), m_[3])};     \
+        pk_ = u32x4{cvt_pk_min(v0_[0], v0_[1], m_[0]), cvt_pk_min(v0_[2], v0_[3], m_[1]),                      \
+                    cvt_pk_min(v1_[0], v1_[1], m_[2]), cvt_pk_min(v1_[2], v1_[3], m_[3])};                     \
     }
 // one group: the MFMAs of a channel block behind the packing of the next one.  Two copies of this code, for whole groups (no
 // mask) and for the others; where the two paths merge the register allocator may copy accumulators -- PMX_MFS / PMX_SETTLE

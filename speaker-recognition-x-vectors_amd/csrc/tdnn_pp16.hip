@@ -1050,9 +1050,17 @@ __device__ __forceinline__ void process_tile(const TdnnArgs& a, char* smem, Stre
             sh = *reinterpret_cast<const float4*>(cst_e + 512);
             bi_e = *reinterpret_cast<const float4*>(cst_e);
         }
+        // Row (32 i + 16 f + e) of the wave's part of the tile: the 32 i go into the scalar offset, the 16 f + e into EIGHT lane
+        // offsets made here from the opaque lane id.  (All 32 row offsets as scalars: loop-invariant, so hipcc computed them
+        // before the tile loop, ran out of SGPRs, parked them in VGPR lanes and fetched each with v_readlane_b32 + s_nop 4
+        // in front of its store.)
+        int y_vo[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) y_vo[j] = y_voff + (16 * (j >> 2) + (j & 3)) * a.ldy * 2;
 #define PP_STORE_F(i_, f_)                                                                             \
             _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                               \
-                const int so_ = (ln.grp * 32 * MR + 32 * i_ + 16 * f_ + e) * a.ldy * 2;                   \
+                const int so_ = (ln.grp * 32 * MR + 32 * i_) * a.ldy * 2;                                 \
+                const int y_voff = y_vo[4 * f_ + e];                                                      \
                 if constexpr (!X3) {                                                                      \
                     const u32x2 pk = {relu_pk_bf16(__builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{acc##i_##f_##0[e], acc##i_##f_##1[e]}, bf16x2))), \
                                       relu_pk_bf16(__builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{acc##i_##f_##2[e], acc##i_##f_##3[e]}, bf16x2)))}; \

@@ -93,7 +93,7 @@ typedef struct {
 int xvec_create(const xvec_cfg* cfg, xvec_handle** out);
 void xvec_destroy(xvec_handle* h);
 const char* xvec_last_error(void);
-/* "gfx950 hip <build id>" */
+/* "xvec_hip gfx950 build <id>": id = hash of the sources the library was built from (csrc/Makefile, BUILD_ID) */
 const char* xvec_version(void);
 
 /* ---- parameters (replaces nn.Module state: load_state_dict, main.py:213) -------------

@@ -517,7 +517,10 @@ int common_checks(xvec_handle* h, const void* x, int B, int mode, int dtype, con
 extern "C" {
 
 const char* xvec_last_error(void) { return g_err; }
-const char* xvec_version(void) { return "xvec_hip gfx950 0.1 (" __DATE__ ")"; }
+#ifndef XVEC_BUILD_ID
+#define XVEC_BUILD_ID "unknown"
+#endif
+const char* xvec_version(void) { return "xvec_hip gfx950 build " XVEC_BUILD_ID; }
 
 int xvec_create(const xvec_cfg* cfg, xvec_handle** out) {
     if (!cfg || !out) return fail(XVEC_ERR_ARG, "null argument");

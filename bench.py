@@ -472,6 +472,19 @@ def main():
         m16w = m16w.to(dev).eval()
         secondary["wave_bf16_utt_per_s"] = round(B / timed(lambda: m16w.extract_x_vec(fe2(wv)), K4), 1)
         del m16w
+        # ... and with the boundary handing over HOST waveforms (the reference's producer is host-side, dataset.py:124-128):
+        # pinned fp32 [B, 48000] batches through the product's overlapped pipeline (extract.stream_x_vectors: H2D on a side
+        # stream, MFCC + path on the compute stream, results to pinned host buffers); 49 MB per batch over PCIe
+        wv_host = wv.cpu().pin_memory()
+        n_w = 30
+        for _ in xa.extract.stream_x_vectors(model, (wv_host for _ in range(n_w)), prepare=fe2):      # warm the rings (see extras())
+            pass
+        torch.cuda.synchronize(dev)
+        t_w = time.perf_counter()
+        for _ in xa.extract.stream_x_vectors(model, (wv_host for _ in range(n_w)), prepare=fe2):
+            pass
+        torch.cuda.synchronize(dev)
+        secondary["wave_pcie_inclusive_utt_per_s"] = round(n_w * B / (time.perf_counter() - t_w), 1)
         secondary["mfcc_us_per_batch"] = round(timed(lambda: fe2(wv), 50, 0.05) * 1e6, 2)
         secondary["mfcc_algorithmic_gb_per_s"] = round(B * (48000 * 4 + 299 * 24 * 4) / (secondary["mfcc_us_per_batch"] * 1e-6) / 1e9, 1)
         n_sc = 4874                                                    # VoxCeleb1 test set (plda_score_stat.py:19-20: every x-vector against every other)
@@ -481,9 +494,21 @@ def main():
         secondary["plda_score_ms_n4874"] = round(timed(lambda: scorer.score(xs), 10, 0.05) * 1e3, 4)
         secondary["plda_gemm_tflops_f64"] = round(2.0 * n_sc * n_sc * 512 / (secondary["plda_score_ms_n4874"] * 1e-3) / 1e12, 1)
 
+    def job_leg():
+        """configs[3] at its own size on this one GPU (the N = 1 anchor of the scaling curve): 100 000 utterances generated
+        on the device batch by batch through the product's sharded job (extract.extract_sharded, one rank: no exchange)."""
+        n_job = 100_000
+        t_j = time.perf_counter()
+        full = xa.extract.extract_sharded(
+            model.extract_x_vec, lambda lo, hi: torch.randn((hi - lo, T, 24), generator=gen, device=dev, dtype=torch.float32),
+            n_job, batch_size=B)
+        torch.cuda.synchronize(dev)
+        assert full.shape == (n_job, 512)
+        secondary["job100k_embeddings_per_s"] = round(n_job / (time.perf_counter() - t_j), 1)
+
     if (world == 1 and not args.force_collective and not args.no_secondary and args.workload == "fixed"
             and args.dtype == "fp32"):
-        for leg in (secondary_legs, next_row_legs):
+        for leg in (secondary_legs, next_row_legs, job_leg):
             try:
                 leg()
             except Exception as e:      # noqa: BLE001
@@ -549,6 +574,7 @@ def main():
                            "job": f"configs[3]: {args.utterances} utterances of {T} frames generated on the device batch by "
                                   f"batch ({B}), sharded over {world} rank(s), {args.dtype}, "}[args.workload]
                                    + "extract_x_vec layer 6, random-init weights seed 42",
+                       "build": xa.hip.version(),
                        "batch_per_gpu": B, "frames": T, "valid_frames_per_s": round(frames_done / dt, 1),
                        "pcie_inclusive_embeddings_per_s_per_gpu": round(K_pcie * B / dt_pcie, 1) if dt_pcie else None,
                        "graph_replay_embeddings_per_s_per_gpu": round(K * B / dt_graph, 1) if dt_graph else None,

@@ -16,6 +16,10 @@ for path in sorted(glob.glob(os.path.join(root, "**", "*counter_collection.csv")
             if "xvec::" not in k and "mfcc" not in k:       # (the MFCC kernels live in an anonymous namespace)
                 continue
             k = k.replace("void xvec::", "").replace("void ", "").replace("(xvec::TdnnArgs)", "").replace("(anonymous namespace)::", "").split("(")[0]
+            # the fp64 score GEMM runs at two very different sizes in one PLDA score (two [n,512] x [512,512] products, then
+            # the [n,n] score matrix): one entry per grid, not an average over both
+            if "gemm_nt_f64_kernel" in k:
+                k += f" [grid {int(row['Grid_Size']) // max(int(row['Workgroup_Size']), 1)}]"
             agg[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
 # HBM traffic per launch, corrected as MI355X_MICROARCH.md (HBM section) prescribes for gfx950:
 # FETCH_SIZE (KiB) under-reports wide coalesced reads by exactly 2x, WRITE_SIZE (KiB) is exact.

@@ -495,21 +495,31 @@ __global__ __launch_bounds__(256, 4) void mfcc512_kernel(const float* __restrict
         }
         __syncthreads();                                            // P and en complete
         // ---- mel filterbank: this wave's share of the (filter tile, bin group) products
+        // Independent accumulators, the k-steps outermost: an MFMA's accumulator is then two or three MFMAs old when the next
+        // one needs it (v_mfma_f32_16x16x4_f32: 32 cycles to issue, 40 until a dependent one may start).  Round 4 chained all
+        // twenty MFMAs of a wave through two accumulators: twenty waits of one MFMA's latency per tile with nothing between
+        // them.  Two rounds (products 0-2, then 3-4): all five at once needs 40 registers and spills.  (Products past n_items
+        // have all-zero B fragments and read P columns that exist: they add exact zeros and are left out of the sums.)
         f32x4v acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < kMaxItems; ++s) {
-            const int it = wave + 4 * s;
-            if (it < n_items) {                                     // uniform
-                const f32x4v a = *reinterpret_cast<const f32x4v*>(P + row * kPS + a_off[s] + 4 * q);
-                if (it < d.f_n0) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], fb[s][j], acc0, 0, 0, 0);
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], fb[s][j], acc1, 0, 0, 0);
-                }
-            }
+#define MF_FB_ROUND(S0_, N_)                                                                                       \
+        {                                                                                                          \
+            f32x4v pa[N_], pacc[N_];                                                                               \
+            _Pragma("unroll") for (int s = 0; s < N_; ++s) {                                                       \
+                pa[s] = *reinterpret_cast<const f32x4v*>(P + row * kPS + a_off[S0_ + s] + 4 * q);                  \
+                pacc[s] = f32x4v{0.f, 0.f, 0.f, 0.f};                                                              \
+            }                                                                                                      \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                          \
+                _Pragma("unroll") for (int s = 0; s < N_; ++s)                                                     \
+                    pacc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[s][j], fb[S0_ + s][j], pacc[s], 0, 0, 0);     \
+            _Pragma("unroll") for (int s = 0; s < N_; ++s) {        /* in product order */                         \
+                const int it = wave + 4 * (S0_ + s);                                                               \
+                if (it < d.f_n0) acc0 += pacc[s];                   /* uniform */                                  \
+                else if (it < n_items) acc1 += pacc[s];                                                            \
+            }                                                                                                      \
         }
+        MF_FB_ROUND(0, 3)
+        MF_FB_ROUND(3, 2)
+#undef MF_FB_ROUND
         // partial sums into the wave's (now idle) exchange region
         reinterpret_cast<f32x4v*>(ex)[lane] = acc0;
         reinterpret_cast<f32x4v*>(ex)[64 + lane] = acc1;

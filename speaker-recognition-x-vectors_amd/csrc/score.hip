@@ -19,9 +19,13 @@ typedef double f64x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kSM = 128;   // block tile rows (of A)
 constexpr int kSN = 128;   // block tile cols (rows of B)
-constexpr int kSK = 16;    // K chunk: 16 doubles = one 128-byte row piece
-constexpr int kSLD = 18;   // LDS row stride in doubles (144 B): ds_read_b64 fragments of 16 rows x 2 k
-                           // then hit 32 distinct even banks, and rows stay 16-byte aligned
+constexpr int kSK = 16;    // K chunk: 16 doubles = one 128-byte row = eight 16-byte pairs (k = 2c, 2c+1 in pair c)
+constexpr int kSLD = 16;   // LDS row stride in doubles: 128 B, no padding.  Pair c of row r sits at position c ^ ((r >> 1) & 7)
+                           // (the swizzle of tdnn_pp16.hip): a ds_read_b128 service group -- 16 lanes on 16 different rows,
+                           // eight of them one pair further on -- then covers all 64 banks, and the eight lanes of a
+                           // ds_write_b128 group fill one whole row.  (Round 4 padded rows to 144 B for ds_read_b64 fragments;
+                           // hipcc merged those into ds_read2_b64 -- banks mod 32, 16-lane groups: rows r and r + 8 collided,
+                           // SQ_LDS_BANK_CONFLICT 40 % of SQ_LDS_IDX_ACTIVE, and the LDS as busy as the matrix pipe.)
 
 struct GemmArgs {
     const double* A;
@@ -79,13 +83,18 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(const GemmArgs g) {
             rb[p] = load2<VEC>(g.B, g.ldb, g.N, g.K, n0 + row0 + 32 * p, k0 + 2 * piece);
         }
     };
+    const int wpos = 2 * (piece ^ ((row0 >> 1) & 7));       // (row0 + 32 p) >> 1 & 7 is the same for every p
     auto lstore = [&](int buf) {
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
-            *reinterpret_cast<f64x2*>(sA + (buf * kSM + row0 + 32 * p) * kSLD + 2 * piece) = ra[p];
-            *reinterpret_cast<f64x2*>(sB + (buf * kSN + row0 + 32 * p) * kSLD + 2 * piece) = rb[p];
+            *reinterpret_cast<f64x2*>(sA + (buf * kSM + row0 + 32 * p) * kSLD + wpos) = ra[p];
+            *reinterpret_cast<f64x2*>(sB + (buf * kSN + row0 + 32 * p) * kSLD + wpos) = rb[p];
         }
     };
+    // fragment reads: lane (l15, l4) takes pair l4 (k = 2 l4, 2 l4 + 1) and pair l4 + 4 of its row; an MFMA's four k (one per
+    // lane quad) are then {0,2,4,6}, {1,3,5,7}, {8,..}, {9,..} -- the same permutation in both operands, so the products pair up
+    const int rsw = (l15 >> 1) & 7;                         // rows wr*64 + 16 i + l15: the swizzle depends on l15 only
+    const int rpos0 = 2 * (l4 ^ rsw), rpos1 = 2 * ((l4 + 4) ^ rsw);
 
     const int n_chunks = (g.K + kSK - 1) / kSK;
     gload(0);
@@ -99,21 +108,24 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(const GemmArgs g) {
     for (int c = 0; c < n_chunks; ++c) {
         const int buf = c & 1;
         if (c + 1 < n_chunks) gload((c + 1) * kSK);
-        const double* a_base = sA + (buf * kSM + wr * 64 + l15) * kSLD + l4;
-        const double* b_base = sB + (buf * kSN + wc * 64 + l15) * kSLD + l4;
+        const double* a_base = sA + (buf * kSM + wr * 64 + l15) * kSLD;
+        const double* b_base = sB + (buf * kSN + wc * 64 + l15) * kSLD;
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            double a[4], b[4];
+        for (int h = 0; h < 2; ++h) {
+            f64x2 a[4], b[4];
+            const int rp = h ? rpos1 : rpos0;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                a[i] = a_base[i * 16 * kSLD + kk * 4];
-                b[i] = b_base[i * 16 * kSLD + kk * 4];
+                a[i] = *reinterpret_cast<const f64x2*>(a_base + i * 16 * kSLD + rp);
+                b[i] = *reinterpret_cast<const f64x2*>(b_base + i * 16 * kSLD + rp);
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int e = 0; e < 2; ++e)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
         }
         if (c + 1 < n_chunks) lstore(buf ^ 1);
         __syncthreads();

@@ -163,7 +163,8 @@ def _side_streams(dev):
     return _SIDE[key]
 
 
-def stream_x_vectors(model, host_batches: Iterable[torch.Tensor], device=None, depth: int = 3):
+def stream_x_vectors(model, host_batches: Iterable[torch.Tensor], device=None, depth: int = 3,
+                     prepare: Callable[[torch.Tensor], torch.Tensor] = None):
     """Overlapped extraction from HOST batches: yields the fp32 [B, D] x-vectors of every batch as
     host tensors, in input order.
 
@@ -184,7 +185,10 @@ def stream_x_vectors(model, host_batches: Iterable[torch.Tensor], device=None, d
     90.1 k resident), here it is not (profiles/diag/stream_probe3.py) -- host wake-up latencies differ
     between boxes, so the loop must not depend on them.
     Host batches may be pinned or pageable, and float64 (what the reference's DataLoader yields,
-    main.py:137): the cast to fp32 happens on the device, as in test_step."""
+    main.py:137): the cast to fp32 happens on the device, as in test_step.
+    `prepare`: a device-side step between the copy and the path, e.g. an MfccFrontEnd when the host batches are raw
+    waveforms [B, n_samples] (the reference computes its MFCCs on the host, dataset.py:124-128; here 192 KB of samples per
+    3 s utterance cross PCIe instead of 28.7 KB of features, and the features never leave the device)."""
     dev = torch.device(device) if device is not None else next(model.parameters()).device
     if dev.type != "cuda":
         raise RuntimeError("stream_x_vectors: the model must live on a HIP device")
@@ -240,7 +244,7 @@ def stream_x_vectors(model, host_batches: Iterable[torch.Tensor], device=None, d
                 arrived = arrived_ev[i]
                 arrived.record(h2d)
             compute.wait_event(arrived)
-            out = model.extract_x_vec(slots[i])        # enqueued on the current stream
+            out = model.extract_x_vec(prepare(slots[i]) if prepare is not None else slots[i])   # enqueued on the current stream
             done = done_ev[i]
             done.record(compute)
             consumed[i] = done

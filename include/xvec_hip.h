@@ -153,6 +153,21 @@ int xvec_stat_pool(const float* x, const int32_t* lengths_dev, int32_t B, int32_
 int xvec_affine(xvec_handle* h, int which, const float* x, int32_t M, int relu, float* y,
                 xvec_stream stream);
 
+/* ---- test introspection -------------------------------------------------------------
+ * Where the regions of a workspace lie that a test may want to look into after a call (tests/test_segmx_exact_gpu.py reads
+ * layer 5's pooling partials): byte offsets for a batch of n_utts utterances totalling total_frames frames, exactly as
+ * xvec_forward / xvec_tdnn_pool_layer lay them out.  Nothing in the product calls this.
+ *   part:     pooling partials [part_slots][3 planes K | S1 | S2][pool_n_pad] fp32 (csrc/tdnn_common.h; which slot holds
+ *             what depends on the kernel layer 5 went to: xvec_get_dispatch)
+ *   part_cnt: int32 frames behind each segment partial of the large-batch kernel (csrc/tdnn_pp16.hip)
+ *   act_a / act_b: the two frame-level activation buffers, rows_alloc rows each (the per-stage entries stage their input in act_a) */
+typedef struct {
+    size_t act_a, act_b, part, part_cnt, pooled, bytes;
+    int64_t rows_alloc, part_slots;
+    int32_t pool_n_pad, hidden_n_pad, num_cu;
+} xvec_ws_layout;
+int xvec_workspace_layout(const xvec_handle* h, int64_t total_frames, int32_t n_utts, xvec_ws_layout* out);
+
 /* ---- measurement --------------------------------------------------------------------
  * With profiling on, xvec_forward brackets every kernel with hipEvents on the caller's
  * stream.  xvec_get_timings synchronises on the last event and returns milliseconds:

@@ -678,6 +678,23 @@ size_t xvec_workspace_bytes(const xvec_handle* h, int64_t total_frames, int32_t 
     return make_plan(h, total_frames, n_utts).bytes;
 }
 
+int xvec_workspace_layout(const xvec_handle* h, int64_t total_frames, int32_t n_utts, xvec_ws_layout* out) {
+    if (!h || !out || total_frames < 1 || n_utts < 1) return fail(XVEC_ERR_ARG, "bad argument");
+    const Plan p = make_plan(h, total_frames, n_utts);
+    out->act_a = p.actA;
+    out->act_b = p.actB;
+    out->part = p.part;
+    out->part_cnt = p.part_cnt;
+    out->pooled = p.pooled;
+    out->bytes = p.bytes;
+    out->rows_alloc = p.rows_alloc;
+    out->part_slots = p.part_slots;
+    out->pool_n_pad = h->geo[4].n_pad;
+    out->hidden_n_pad = h->geo[0].n_pad;
+    out->num_cu = h->num_cu;
+    return XVEC_OK;
+}
+
 int xvec_forward(xvec_handle* h, const float* x, const int32_t* lengths_host, int32_t B, int32_t T, int mode,
                  int dtype, float* out, void* workspace, size_t workspace_bytes, xvec_stream stream) {
     int rc = common_checks(h, x, B, mode, dtype, out, workspace);

@@ -48,6 +48,12 @@ class MfccCfg(C.Structure):
                 ("device", C.c_int32)]
 
 
+class WsLayout(C.Structure):
+    _fields_ = [("act_a", C.c_size_t), ("act_b", C.c_size_t), ("part", C.c_size_t), ("part_cnt", C.c_size_t),
+                ("pooled", C.c_size_t), ("bytes", C.c_size_t), ("rows_alloc", C.c_int64), ("part_slots", C.c_int64),
+                ("pool_n_pad", C.c_int32), ("hidden_n_pad", C.c_int32), ("num_cu", C.c_int32)]
+
+
 class Cfg(C.Structure):
     _fields_ = [("input_size", C.c_int32), ("hidden_size", C.c_int32), ("num_classes", C.c_int32),
                 ("x_vector_size", C.c_int32), ("batch_norm", C.c_int32), ("device", C.c_int32)]
@@ -70,6 +76,7 @@ _SIGS = {
     "xvec_load_tdnn": (C.c_int, [_vp, C.c_int, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_float, _vp]),
     "xvec_load_affine": (C.c_int, [_vp, C.c_int, _f32p, _f32p, _vp]),
     "xvec_workspace_bytes": (C.c_size_t, [_vp, _i64, _i32]),
+    "xvec_workspace_layout": (C.c_int, [_vp, _i64, _i32, C.POINTER(WsLayout)]),
     "xvec_forward": (C.c_int, [_vp, _f32p, C.POINTER(_i32), _i32, _i32, C.c_int, C.c_int, _f32p, _vp,
                                C.c_size_t, _vp]),
     "xvec_forward_packed": (C.c_int, [_vp, _f32p, C.POINTER(_i64), _i32, C.c_int, C.c_int, _f32p, _vp,

@@ -67,7 +67,10 @@ def test_random_shapes_large_batch_vs_128x128(engines, synth, gpu_model, precisi
     if ragged:
         short[torch.as_tensor([n - 14 < 4 for n in lengths])] = True
     assert_parity_masked(got, old, tight, f"{precision} pooled B={B} T={T} ragged={ragged}",
-                         2e-2 if precision == "bf16" else 10 * tight, short, max_excluded=0.1)
+                         2e-2 if precision == "bf16" else 10 * tight, short,
+                         # exactly the one 16-frame utterance of a ragged batch (profiles/r05_mask_shares.txt: 1 / B of the rows in
+                         # every case of a full run); 1.5 x that, and nothing in a fixed-length batch
+                         max_excluded=1.5 / B if ragged else 0.0)
     assert_parity(m_pp.extract_x_vec(x, lengths=lengths), m_old.extract_x_vec(x, lengths=lengths), tight,
                   f"{precision} x-vectors B={B} T={T} ragged={ragged}", elem_tol=10 * tight)
     # and against the exact fp32 path at the precision's own bar

@@ -137,7 +137,8 @@ def test_bf16_fused_pooling_layer(gpu_model, sd42, synth, models, B, T):
     assert m_old.last_dispatch()[4] == "tile128"
     # (the large-batch kernel sums bf16-rounded deviations on the matrix pipe -- tdnn_pp16.hip, SegMx: 2^-9 of random error
     #  per frame and value, ~1e-4 of a statistic over 286 frames -- the 128x128 kernel fp32 ones; a single corrupted frame
-    #  moves a mean by 1/286 = 3.5e-3 of a value)
+    #  moves a mean by 1/286 = 3.5e-3 of a value, which THIS bound cannot see: tests/test_segmx_exact_gpu.py checks the sums
+    #  themselves, with the rounding taken out, at two and a half bf16 steps of one deviation)
     assert_parity(got, old, 1e-3, f"pooled B={B} T={T}: large-batch vs 128x128 kernel", elem_tol=5e-3)
     idx = sorted({0, 1, B // 3, B // 2, B - 2, B - 1})
     frames = torch.cat([_oracle_layer(h[j:j + 1].cpu(), p64, 4).double() for j in idx])
@@ -145,10 +146,10 @@ def test_bf16_fused_pooling_layer(gpu_model, sd42, synth, models, B, T):
     assert_parity(got[idx], ref, 1e-2, f"pooled B={B} T={T} vs oracle")
     # the std half alone, element by element at the bf16 bar -- except the nearly-off channels (a handful of frames above
     # zero: they carry the bf16 rounding of layer 4's output at 5-10 % of their tiny std, in the fp32 reference's own
-    # bf16-rounded run too), which are LISTED (at most 0.1 % of the elements), not covered by a wide tolerance
+    # bf16-rounded run too), which are LISTED (1.1 % of the elements at most, measured; the limit is 1.5 x that), not covered by a wide tolerance
     off = nearly_off_channels(_pre_bn(frames, sd42, 4), ref[:, 1500:])
     assert_parity_masked(got[idx][:, 1500:], ref[:, 1500:], 1e-2, f"std half alone B={B} T={T}", 2e-2, off,
-                         atol_scale=ref.abs().mean().item())
+                         atol_scale=ref.abs().mean().item(), max_excluded=1.7e-2)   # measured: <= 1.11e-2 (profiles/r05_mask_shares.txt)
     # the fp32 kernel's fused pooling on the same input, every utterance
     assert_parity(got, gpu_model.pooled_last_layer(h), 1e-2, "vs fp32 fused pooling")
 
@@ -327,5 +328,5 @@ def test_fp32_every_layer_every_element_at_the_bench_size(gpu_model, sd42, synth
             pre = got.cpu().double() @ p64["time_context_layers.4.linear.weight"].T + p64["time_context_layers.4.linear.bias"]
             off = nearly_off_channels(_pre_bn(frames, sd42, 4), ref[:, 1500:], pre)
             assert_parity_masked(pooled[:, 1500:], ref[:, 1500:], 1e-4, "fp32 pooled stds, B=256", 1e-4, off,
-                                 atol_scale=ref.abs().mean().item())
+                                 atol_scale=ref.abs().mean().item(), max_excluded=1.5e-2)   # measured: 1.00e-2 (profiles/r05_mask_shares.txt)
         h = got

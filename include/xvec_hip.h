@@ -55,7 +55,12 @@ enum {
     XVEC_BF16 = 1,  /* bf16 activations and weights (parity bar 1e-2).  Between layers this mode keeps the ReLU outputs (bf16) and
                      * DEFERS each layer's eval BatchNorm (tdnn_layer.py:36-39) into the next layer's weights and bias -- an affine
                      * map of a valid convolution's input folds exactly; layer 5's goes to the pooling merge.  The per-layer entry
-                     * points below still take and return the reference's tensors (BatchNorm applied). */
+                     * points below still take and return the reference's tensors (BatchNorm applied): they take x back through the
+                     * producing layer's BatchNorm, r = (x - shift) / scale; a channel whose folded scale is 0 (gamma = 0) or below
+                     * 1e-18 in magnitude is read as x = shift, which is what the reference's BatchNorm gives there for any r.
+                     * Pooling in this mode sums bf16-rounded deviations about ONE pivot per block of ~27 x 64 frames, so the same
+                     * utterance gives x-vectors that differ by up to ~1e-3 (bar 1e-2) with its position in the batch, the batch's
+                     * make-up and the way a job is cut into calls; XVEC_F32 / XVEC_BF16X3: <= 1e-5.  Repeat calls are bit-identical. */
     /* fp32 values carried as two bf16 planes (hi + lo), three bf16 products per k-step
      * (x_hi*W_hi + x_lo*W_hi + x_hi*W_lo; every product is exact in the fp32 accumulator, what is
      * dropped is 2^-16 relative): fp32-level results (parity bar 1e-4, as XVEC_F32) at bf16 matrix rates */
@@ -102,6 +107,9 @@ const char* xvec_version(void);
  *   layer 0..4: time_context_layers.{layer}.linear.{weight[out, in*|ctx|], bias[out]}
  *               time_context_layers.{layer}.norm.{weight,bias,running_mean,running_var}[out]
  *               (all four NULL when cfg.batch_norm == 0); eps = BatchNorm1d.eps (1e-5). */
+/* All xvec_load_* calls of a handle must be issued on ONE stream, or be synchronised with each other by the caller: loading
+ * layer l also re-packs the bf16 copies of layer l + 1 (whose weights carry layer l's BatchNorm in XVEC_BF16) from the raw
+ * weights an earlier xvec_load_tdnn(l + 1) left on ITS stream. */
 int xvec_load_tdnn(xvec_handle* h, int layer, const float* weight, const float* bias,
                    const float* bn_weight, const float* bn_bias, const float* bn_mean,
                    const float* bn_var, float eps, xvec_stream stream);

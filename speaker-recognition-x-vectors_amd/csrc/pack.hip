@@ -206,7 +206,9 @@ hipError_t launch_patch_bias_kslots(const float* bias, const TdnnGeom& geo, void
 
 // x[B,T,C] -> packed rows out[offsets[u] + t][c_pad] for t < len_u (zero padded channels).
 // un_scale / un_shift (or nullptr): the folded BatchNorm of the layer that PRODUCED x, inverted on the way in --
-// r = (x - shift) / scale, 0 where scale == 0 (such a channel meets zero folded weights) -- for the per-layer entries in
+// r = (x - shift) / scale, 0 where |scale| < 1e-18 (gamma = 0 or denormal-small: the reference's BatchNorm output is then
+// x = shift whatever r was, the channel meets folded weights W * scale that are zero or about to flush, and the quotient
+// would overflow to Inf -- Inf * 0 = NaN) -- for the per-layer entries in
 // plain bf16, whose kernels read the producing layer's relu output and carry its BatchNorm in their weights.
 template <typename TO>
 __global__ void pack_rows_kernel(const float* __restrict__ x, const int64_t* __restrict__ offsets, int T,
@@ -225,7 +227,7 @@ __global__ void pack_rows_kernel(const float* __restrict__ x, const int64_t* __r
         float v = (c < C) ? src[t * C + c] : 0.f;
         if (un_scale && c < C) {
             const float sc = un_scale[c];
-            v = sc != 0.f ? (v - un_shift[c]) / sc : 0.f;
+            v = fabsf(sc) >= 1e-18f ? (v - un_shift[c]) / sc : 0.f;
         }
         dst[i] = (TO)v;
     }

@@ -271,6 +271,44 @@ def test_ill_conditioned_pooling_through_the_fused_path(sd42, synth, precision, 
     assert_parity(gr[:, 1500:], rr[:, 1500:], tol, f"{precision} ragged stds", elem_tol=4e-2 if precision == "bf16" else None)
 
 
+@pytest.mark.parametrize("precision,B,tol", [("fp32", 12, 1e-4), ("bf16x3", 24, 1e-4), ("bf16", 24, 1e-2)])
+def test_pooling_pivot_taken_from_a_neighbouring_utterance(sd42, precision, B, tol):
+    """the pooling pivot is ONE per (block, channel) -- the block's first frame (fp32 128x128 kernel, tdnn_layer.hip)
+    or one per wave for the whole block (plain bf16, tdnn_pp16.hip SegMx) -- so an utterance is summed about a NEIGHBOUR's frame
+    whenever it does not open the block.  The sums then lose ~1e-7 ((mean - K) / std)^2 of the variance in fp32 (2^-9 (mean - K)
+    of random rounding per frame on bf16 deviations).  Here low-variance channels sit at levels that differ between utterances
+    by up to 21 of their within-utterance std -- means and stds of every utterance must still meet the precision's bar.
+    (The envelope: at 45 std fp32 reaches its 1e-4, at ~80 plain bf16 its 1e-2; within ONE utterance the pivot cannot be
+    further than sqrt(n) std from the mean, it is one of the n frames.  DESIGN section 2.)
+    Layer 5 is made a two-tap mix of its input channels (bf16-exact weights, no bias), layer 4's BatchNorm the identity, and
+    the input is bf16-exact: every arithmetic sees the same numbers and the fp64 reference is exact."""
+    sd = {k: v.clone() for k, v in sd42.items()}
+    p = "time_context_layers.3.norm."
+    sd[p + "weight"].fill_(1.0); sd[p + "bias"].zero_(); sd[p + "running_mean"].zero_(); sd[p + "running_var"].fill_(1.0 - 1e-5)
+    W = torch.zeros_like(sd["time_context_layers.4.linear.weight"])
+    c = torch.arange(512)
+    W[c, c] = 1.0
+    W[c, (c + 1) % 512] = 77.0 / 256.0
+    sd["time_context_layers.4.linear.weight"] = W
+    sd["time_context_layers.4.linear.bias"].zero_()
+    m = _model(sd, precision)
+    rng = np.random.default_rng(B)
+    T = 300
+    level = 12 * rng.choice([-1, 1], size=(B, 1, 512))                     # per (utterance, channel): +-12 steps of 2^-7
+    h = torch.from_numpy(((128 + level + rng.integers(-2, 3, size=(B, T, 512))) / 128.0).astype(np.float32))
+    assert torch.equal(h, h.bfloat16().float())
+    got = m.pooled_last_layer(h.to(DEV))
+    p64 = oracle.cast_params(float_params(sd), torch.float64)
+    ref = oracle.stat_pool(_oracle_layer(h, p64, 4).double())
+    z = h.double() @ W[:512].double().T
+    sep = ((z.mean(1)[:, None] - z.mean(1)[None]).abs() / z.std(1)[None]).amax()      # level distance between utterances, in stds
+    assert 15 < float(sep) < 30, float(sep)
+    live = slice(0, 512)                                                   # channels 512.. are constant zero: mean = shift, std = 0
+    assert_parity(got[:, :1500], ref[:, :1500], tol, f"{precision} means, pivots up to {float(sep):.0f} std away")
+    assert_parity(got[:, 1500:][:, live], ref[:, 1500:][:, live], tol, f"{precision} stds, pivots up to {float(sep):.0f} std away")
+    assert_parity(got[:, 1500:], ref[:, 1500:], tol, f"{precision} stds (all channels)")
+
+
 @pytest.mark.parametrize("B", [64, 200])
 def test_bf16_ragged_large_batches_pooled(gpu_model, sd42, synth, models, B):
     """Ragged batches on the large-batch kernels (set_rows<RAGGED>, tdnn_first_kernel<true>, the pooling cursor on

@@ -38,6 +38,7 @@ size_t xvec_score_workspace_bytes(int64_t n_enroll, int64_t n_test, int32_t dim)
 /* fast_PLDA_scoring (speechbrain.processing.PLDA_LDA, as called at plda_classifier.py:86):
  *   e = enroll - mean, t = test - mean
  *   scores[i,j] = scaling * ( 0.5 e_i' Phi e_i + 0.5 t_j' Phi t_j + e_i' Psi t_j + plda_cst )
+ * (when phi_t == psi_t + dim*dim, i.e. the caller keeps [Psi^T ; Phi^T] stacked in one buffer, [e Psi | e Phi] is formed in one launch)
  * psi_t / phi_t are the TRANSPOSES of Psi / Phi ([dim,dim], row-major), plda_cst the Gaussian
  * constant; the host derives them from (F, Sigma) once per model (scoring.PldaScorer).
  * test == NULL scores enroll against itself (the reference's use: plda_score_stat.py:19-20). */

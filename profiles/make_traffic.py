@@ -21,7 +21,8 @@ nxt = out.get("next_rows")
 if nxt:
     n, dim = 4874, 512
     alg = {"mfcc512_kernel": 256 * (48000 * 4 + 299 * 24 * 4),              # 256 waveforms of 3 s in, [256, 299, 24] out
-           "gemm_nt_f64_kernel<true> [grid 512]": (2 * n * dim + n * n) * 8}    # the [n, n] score matrix: two operands in, scores out
+           "gemm_nt_f64_kernel<true, 4> [grid 512]": (2 * n * dim + n * n) * 8,   # the [n, n] score matrix: two operands in, scores out
+           "gemm_nt_f64_kernel<true, 2> [grid 512]": (n * dim + 2 * dim * dim + 2 * n * dim) * 8}   # [e Psi | e Phi]: e and the stacked matrices in, [n, 2 dim] out
     for key, ent in nxt.items():
         for frag, b in alg.items():
             if isinstance(ent, dict) and frag in key:

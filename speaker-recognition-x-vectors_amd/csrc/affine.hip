@@ -359,6 +359,17 @@ __global__ __launch_bounds__(256) void affine_reduce_kernel(const float* __restr
     if (q >= MN) return;
     float4 v = *reinterpret_cast<const float4*>(b + (int)(q % N));
     int s = 0;
+    if (S == 16) {
+        // the usual split (segment_layer6 at the bench batch): all sixteen partials requested before the first add -- the slabs
+        // were written by other CUs a moment ago, every load is a round trip to another XCD's L2 or beyond, and four at a time
+        // (below) is four such trips in a row.  Same order of additions.
+        float4 p[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) p[j] = *reinterpret_cast<const float4*>(part + j * MN + q);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { v.x += p[j].x; v.y += p[j].y; v.z += p[j].z; v.w += p[j].w; }
+        s = 16;
+    }
     for (; s + 4 <= S; s += 4) {                 // four independent loads in flight, summed in order
         const float4 p0 = *reinterpret_cast<const float4*>(part + (s + 0) * MN + q);
         const float4 p1 = *reinterpret_cast<const float4*>(part + (s + 1) * MN + q);

@@ -17,8 +17,9 @@ namespace {
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 
-constexpr int kSM = 128;   // block tile rows (of A)
-constexpr int kSN = 128;   // block tile cols (rows of B)
+// block tile = (32 WT) x (32 WT) of C: WT = 4 (128 x 128, the score matrix) or 2 (64 x 64: products whose 128 x 128 tiles would not
+// give every block slot of the chip at least a tile and a half -- the two [n, 512] x [512, 512] products in front of a PLDA score
+// matrix are 312 such tiles for 512 slots, and ran at 55 % of the score matrix's rate)
 constexpr int kSK = 16;    // K chunk: 16 doubles = one 128-byte row = eight 16-byte pairs (k = 2c, 2c+1 in pair c)
 constexpr int kSLD = 16;   // LDS row stride in doubles: 128 B, no padding.  Pair c of row r sits at position c ^ ((r >> 1) & 7)
                            // (the swizzle of tdnn_pp16.hip): a ds_read_b128 service group -- 16 lanes on 16 different rows,
@@ -55,13 +56,14 @@ __device__ __forceinline__ f64x2 load2(const double* __restrict__ P, int64_t ld,
     return v;
 }
 
-// 4 waves as 2x2, each 64x64 = 4x4 MFMA tiles of 16x16 (C/D: col = lane&15, row = (lane>>4) + 4*reg).
+// 4 waves as 2x2, each (16 WT) x (16 WT) = WT x WT MFMA tiles of 16x16 (C/D: col = lane&15, row = (lane>>4) + 4*reg).
 // K in 16-wide chunks through double-buffered LDS; the next chunk's global loads are in flight
 // while the 64 MFMAs (64 cycles each) of the current one run, so the kernel is matrix-pipe bound.
 // Persistent (round 3): two blocks per CU walk the tiles with a grid stride, and the first chunk of a block's NEXT tile is
 // requested before the epilogue of the current one, so a tile no longer starts with an exposed memory round trip.
-template <bool VEC>
+template <bool VEC, int WT>
 __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(const GemmArgs g) {
+    constexpr int kSM = 32 * WT, kSN = 32 * WT;
     extern __shared__ __attribute__((aligned(16))) double sm[];
     int tile = xcd_remap(blockIdx.x, gridDim.x);          // the column tiles of one row tile share an XCD's L2
     if (tile >= g.n_tiles) return;
@@ -74,11 +76,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(const GemmArgs g) {
     double* sA = sm;                          // [2][kSM][kSLD]
     double* sB = sm + 2 * kSM * kSLD;         // [2][kSN][kSLD]
 
-    f64x4 acc[4][4];
-    f64x2 ra[4], rb[4];
+    f64x4 acc[WT][WT];
+    f64x2 ra[WT], rb[WT];
     auto gload = [&](int k0) {
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
+        for (int p = 0; p < WT; ++p) {
             ra[p] = load2<VEC>(g.A, g.lda, g.M, g.K, m0 + row0 + 32 * p, k0 + 2 * piece);
             rb[p] = load2<VEC>(g.B, g.ldb, g.N, g.K, n0 + row0 + 32 * p, k0 + 2 * piece);
         }
@@ -86,7 +88,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(const GemmArgs g) {
     const int wpos = 2 * (piece ^ ((row0 >> 1) & 7));       // (row0 + 32 p) >> 1 & 7 is the same for every p
     auto lstore = [&](int buf) {
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
+        for (int p = 0; p < WT; ++p) {
             *reinterpret_cast<f64x2*>(sA + (buf * kSM + row0 + 32 * p) * kSLD + wpos) = ra[p];
             *reinterpret_cast<f64x2*>(sB + (buf * kSN + row0 + 32 * p) * kSLD + wpos) = rb[p];
         }
@@ -102,29 +104,29 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(const GemmArgs g) {
     __syncthreads();
   for (;;) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < WT; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
+        for (int j = 0; j < WT; ++j) acc[i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
     for (int c = 0; c < n_chunks; ++c) {
         const int buf = c & 1;
         if (c + 1 < n_chunks) gload((c + 1) * kSK);
-        const double* a_base = sA + (buf * kSM + wr * 64 + l15) * kSLD;
-        const double* b_base = sB + (buf * kSN + wc * 64 + l15) * kSLD;
+        const double* a_base = sA + (buf * kSM + wr * 16 * WT + l15) * kSLD;
+        const double* b_base = sB + (buf * kSN + wc * 16 * WT + l15) * kSLD;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            f64x2 a[4], b[4];
+            f64x2 a[WT], b[WT];
             const int rp = h ? rpos1 : rpos0;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < WT; ++i) {
                 a[i] = *reinterpret_cast<const f64x2*>(a_base + i * 16 * kSLD + rp);
                 b[i] = *reinterpret_cast<const f64x2*>(b_base + i * 16 * kSLD + rp);
             }
 #pragma unroll
             for (int e = 0; e < 2; ++e)
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < WT; ++i)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
+                    for (int j = 0; j < WT; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
         }
         if (c + 1 < n_chunks) lstore(buf ^ 1);
@@ -142,15 +144,15 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(const GemmArgs g) {
     }
     // ---- epilogue: + rowv[m] + colv[n] + cst, * scale; 16 lanes write 128 contiguous bytes
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int64_t n = en0 + wc * 64 + j * 16 + l15;
+    for (int j = 0; j < WT; ++j) {
+        const int64_t n = en0 + wc * 16 * WT + j * 16 + l15;
         if (n >= g.N) continue;
         const double cv = (g.colv ? g.colv[n] : 0.0) + g.cst;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < WT; ++i) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int64_t m = em0 + wr * 64 + i * 16 + l4 + 4 * r;
+                const int64_t m = em0 + wr * 16 * WT + i * 16 + l4 + 4 * r;
                 if (m < g.M) {
                     const double rv = g.rowv ? g.rowv[m] : 0.0;
                     g.C[m * g.ldc + n] = g.scale * (acc[i][j][r] + rv + cv);
@@ -221,9 +223,6 @@ int check_launch(const char* what) {
 int gemm_nt(const double* A, int64_t lda, const double* B, int64_t ldb, int64_t M, int64_t N, int K,
             const double* rowv, const double* colv, double cst, double scale, double* C, int64_t ldc, hipStream_t s) {
     if (M == 0 || N == 0) return XVEC_OK;
-    const int64_t tm = (M + kSM - 1) / kSM, tn = (N + kSN - 1) / kSN;
-    if (tm * tn > 0x7fffffff) return sfail(XVEC_ERR_ARG, "score matrix too large for one launch");
-    GemmArgs g{A, B, rowv, colv, C, lda, ldb, ldc, M, N, K, (int)tn, (int)(tm * tn), cst, scale};
     static int num_cu_cache[64] = {};          // per device: two persistent blocks per CU
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return sfail(XVEC_ERR_HIP, "hipGetDevice failed");
@@ -233,18 +232,27 @@ int gemm_nt(const double* A, int64_t lda, const double* B, int64_t ldb, int64_t 
         num_cu = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
         if (dev >= 0 && dev < 64) num_cu_cache[dev] = num_cu;
     }
-    const unsigned grid = (unsigned)std::min<int64_t>(tm * tn, 2 * (int64_t)num_cu);
-    const size_t lds = (size_t)2 * (kSM + kSN) * kSLD * sizeof(double);
+    // 128 x 128 tiles unless they would leave the chip's block slots under a tile and a half each: then 64 x 64
+    const int64_t slots = 2 * (int64_t)num_cu;
+    const bool small = ((M + 127) / 128) * ((N + 127) / 128) * 2 < 3 * slots;
+    const int ts = small ? 64 : 128;
+    const int64_t tm = (M + ts - 1) / ts, tn = (N + ts - 1) / ts;
+    if (tm * tn > 0x7fffffff) return sfail(XVEC_ERR_ARG, "score matrix too large for one launch");
+    GemmArgs g{A, B, rowv, colv, C, lda, ldb, ldc, M, N, K, (int)tn, (int)(tm * tn), cst, scale};
+    const unsigned grid = (unsigned)std::min<int64_t>(tm * tn, slots);
+    const size_t lds = (size_t)2 * (ts + ts) * kSLD * sizeof(double);
     const bool vec = (K % 2 == 0) && (lda % 2 == 0) && (ldb % 2 == 0) && (reinterpret_cast<uintptr_t>(A) % 16 == 0) &&
                      (reinterpret_cast<uintptr_t>(B) % 16 == 0);
-    static LdsOptIn opt_v, opt_s;
-    const hipError_t ea = vec ? opt_v.ensure(reinterpret_cast<const void*>(&gemm_nt_f64_kernel<true>), (int)lds)
-                              : opt_s.ensure(reinterpret_cast<const void*>(&gemm_nt_f64_kernel<false>), (int)lds);
-    if (ea != hipSuccess) return sfail(XVEC_ERR_HIP, "hipFuncSetAttribute failed: %s", hipGetErrorString(ea));
-    if (vec)
-        gemm_nt_f64_kernel<true><<<grid, 256, lds, s>>>(g);
-    else
-        gemm_nt_f64_kernel<false><<<grid, 256, lds, s>>>(g);
+#define SCORE_LAUNCH(VEC_, WT_)                                                                                           \
+    {                                                                                                                     \
+        static LdsOptIn opt;                                                                                              \
+        const hipError_t ea = opt.ensure(reinterpret_cast<const void*>(&gemm_nt_f64_kernel<VEC_, WT_>), (int)lds);        \
+        if (ea != hipSuccess) return sfail(XVEC_ERR_HIP, "hipFuncSetAttribute failed: %s", hipGetErrorString(ea));        \
+        gemm_nt_f64_kernel<VEC_, WT_><<<grid, 256, lds, s>>>(g);                                                          \
+    }
+    if (vec) { if (small) SCORE_LAUNCH(true, 2) else SCORE_LAUNCH(true, 4) }
+    else { if (small) SCORE_LAUNCH(false, 2) else SCORE_LAUNCH(false, 4) }
+#undef SCORE_LAUNCH
     return check_launch("gemm_nt_f64_kernel");
 }
 
@@ -313,9 +321,14 @@ int xvec_plda_score(const double* enroll, int64_t n_enroll, const double* test, 
     // centre (StatObject_SB.center_stat1)
     center_rows_kernel<<<1024, 256, 0, s>>>(enroll, mean, n_enroll, dim, p.ec);
     if ((rc = check_launch("center_rows_kernel"))) return rc;
-    // [e Psi | e Phi]: one GEMM against the stacked [Psi^T ; Phi^T] is two calls on the same A
-    if ((rc = gemm_nt(p.ec, dim, psi_t, dim, n_enroll, dim, dim, nullptr, nullptr, 0.0, 1.0, p.uv, 2 * dim, s))) return rc;
-    if ((rc = gemm_nt(p.ec, dim, phi_t, dim, n_enroll, dim, dim, nullptr, nullptr, 0.0, 1.0, p.uv + dim, 2 * dim, s))) return rc;
+    // [e Psi | e Phi]: ONE GEMM against [Psi^T ; Phi^T] when the caller keeps the two stacked in one buffer (the host module
+    // does), otherwise two calls on the same A
+    if (phi_t == psi_t + (size_t)dim * dim) {
+        if ((rc = gemm_nt(p.ec, dim, psi_t, dim, n_enroll, 2 * (int64_t)dim, dim, nullptr, nullptr, 0.0, 1.0, p.uv, 2 * dim, s))) return rc;
+    } else {
+        if ((rc = gemm_nt(p.ec, dim, psi_t, dim, n_enroll, dim, dim, nullptr, nullptr, 0.0, 1.0, p.uv, 2 * dim, s))) return rc;
+        if ((rc = gemm_nt(p.ec, dim, phi_t, dim, n_enroll, dim, dim, nullptr, nullptr, 0.0, 1.0, p.uv + dim, 2 * dim, s))) return rc;
+    }
     const unsigned rb_e = (unsigned)((n_enroll + 3) / 4);
     half_rowdot_kernel<<<rb_e, 256, 0, s>>>(p.uv + dim, 2 * dim, p.ec, dim, n_enroll, dim, p.mp);   // model_part
     if ((rc = check_launch("half_rowdot_kernel"))) return rc;

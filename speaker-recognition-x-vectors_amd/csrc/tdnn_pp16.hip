@@ -132,7 +132,9 @@ __device__ unsigned long long g_pp16_clk[8];               // block 0: s_memtime
 #define PP_KNOCK_MXPK ((XVEC_KNOCK & 512) != 0)  // bit 9: ... without the packing (max / cvt / mask) of the deviations
 #define PP_KNOCK_MXROWS ((XVEC_KNOCK & 1024) != 0) // bit 10: ... without the groups (restore / fold / park only)
 #define PP_KNOCK_MXFOLD ((XVEC_KNOCK & 4096) != 0) // bit 12: ... without the fold + park at the end of a tile
+#define PP_KNOCK_ATAP ((XVEC_KNOCK & 8192) != 0)   // bit 13: activation pieces requested for tap 0 only (what sharing one slab between a layer's taps would save)
 #else
+#define PP_KNOCK_ATAP false
 #define PP_KNOCK_MXFOLD false
 #define PP_KNOCK_MXMF false
 #define PP_KNOCK_MXPK false
@@ -408,7 +410,7 @@ constexpr int kBlk16 = 16 * kRowB;                // 16 rows of a 32-row block: 
         SB();                                                                       \
         PP_READ_W(b_)                                                               \
         SB();                                                                       \
-        if (req && !PP_KNOCK_DMA) PP_ISSUE_A01(b_, k2.so)                           \
+        if (req && !PP_KNOCK_DMA && !(PP_KNOCK_ATAP && k2.tap != 0)) PP_ISSUE_A01(b_, k2.so) \
         SB();                                                                       \
         PP_WAIT_LGKM();                                                             \
         PP_STAMP(0)                                                                 \
@@ -439,7 +441,7 @@ constexpr int kBlk16 = 16 * kRowB;                // 16 rows of a 32-row block: 
         PP_STAMP(4)                                                                 \
         if (req && !PP_KNOCK_DMA) {                                                 \
             PP_ISSUE_W(b_, wq)                                                      \
-            PP_ISSUE_A23(mr_req, b_, k2.so)                                         \
+            if (!(PP_KNOCK_ATAP && k2.tap != 0)) PP_ISSUE_A23(mr_req, b_, k2.so)    \
         }                                                                           \
         SB();                                                                       \
         PP_STAMP(6)                                                                 \

@@ -98,8 +98,11 @@ class PldaScorer:
         self.scaling_factor = float(scaling_factor)
         self.plda_cst = cst
         self._mean = _dev_f64(mean, self.device)
-        self._psi_t = _dev_f64(psi.T, self.device)
-        self._phi_t = _dev_f64(phi.T, self.device)
+        # Psi^T and Phi^T stacked in ONE [2 dim, dim] buffer: the library then forms [e Psi | e Phi] in one launch
+        # (xvec_plda_score: 2 x 156 tiles of 128 x 128 at 4874 x-vectors fill the 512 block slots better than 156 twice)
+        self._psiphi_t = _dev_f64(np.concatenate([np.asarray(psi).T, np.asarray(phi).T], 0), self.device)
+        self._psi_t = self._psiphi_t[: psi.shape[0]]
+        self._phi_t = self._psiphi_t[psi.shape[0]:]
         self._ws = None
 
     def _workspace(self, ne, nt):

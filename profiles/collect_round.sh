@@ -2,7 +2,7 @@
 # Copy the summaries of one `run_round.sh <tag>` run from gpurun_out/<tag>/ (scratch) into profiles/ (committed):
 #   bash profiles/collect_round.sh r04
 set -e
-tag=${1:-r04}
+tag=${1:-r05}
 cd "$(dirname "$0")/.."
 src=gpurun_out/$tag
 cp $src/bench_fp32.json profiles/${tag}_bench.json

@@ -2,7 +2,7 @@
 # Round profile set (run on the GPU box via gpurun):  bash profiles/run_round.sh <tag>
 #   kernel-trace stats of the default bench line (fp32 + its secondary legs), of --dtype bf16 and of --dtype bf16x3,
 #   FETCH_SIZE / WRITE_SIZE passes for both, utilisation counters for both.  Output: gpurun_out/<tag>/
-tag=${1:-r04}
+tag=${1:-r05}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/$tag

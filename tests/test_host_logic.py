@@ -270,8 +270,10 @@ def test_call_ranges_split_a_batch_that_one_call_cannot_hold():
 def test_traffic_json_is_tied_to_the_built_library():
     """profiles/traffic.json (the PMC bytes bench.py quotes as roofline.traffic; counters cannot be read inside the bench
     process) must describe THIS build: every kernel key bench.py can look up, and every key in the file, is a kernel of the
-    freshly built libxvec_hip.so (demangled symbols), and the file's `source` names the newest committed profile round.
-    Renaming or re-templating a kernel without re-running profiles/run_round.sh turns this red."""
+    freshly built libxvec_hip.so (demangled symbols), the file's `source` names the newest committed profile round, and its
+    `build` is the build id of the library -- the hash of the sources it was made from (csrc/Makefile, BUILD_ID;
+    profiles/build_id.py recomputes it here).  Renaming a kernel OR editing any kernel source without re-running
+    profiles/run_round.sh turns this red."""
     import glob
     import json
     import re
@@ -287,23 +289,35 @@ def test_traffic_json_is_tied_to_the_built_library():
     full = {re.sub(r"__device_stub__", "", m.group(0)[:-1]) for m in re.finditer(r"\S*__device_stub__[^\n]*?\(", syms)}
     assert len(kernels) > 30, "could not list the library's kernels"
     tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "profiles"))
+    import build_id
+    from xvector_amd import hip
+    want_build = f"xvec_hip gfx950 build {build_id.source_build_id()}"
+    assert hip.version() == want_build, f"the built library ({hip.version()}) is not a build of the sources in the tree ({want_build}): run build()"
+    base = lambda key: key.split(" [grid")[0]          # the fp64 GEMM is listed per launch size: "name [grid N]"
     rounds = sorted(int(m.group(1)) for f in glob.glob(os.path.join(ROOT, "profiles", "r*_kernel_stats*.csv"))
                     for m in [re.match(r"r(\d+)_", os.path.basename(f))] if m)
     newest = f"r{rounds[-1]:02d}"
     for dtype in ("fp32", "bf16", "bf16x3"):
         sec = tj[dtype]
         assert f"gpurun_out/{newest}" in sec["source"], f"traffic.json[{dtype}] comes from {sec['source']!r}, newest profile set is {newest}"
+        assert sec.get("build") == want_build, (f"traffic.json[{dtype}] was collected on {sec.get('build')!r}, the tree builds {want_build!r}: "
+                                                "re-run profiles/run_round.sh on the shipped build")
         for pp in (True, False):
             key = bench.traffic_key(dtype, pp)
             assert any(key in k for k in full), f"bench.py's traffic key {key!r} is not a kernel of the built library"
         assert bench.traffic_key(dtype, dtype != "fp32") in sec, f"traffic.json[{dtype}] lacks the dominant kernel of the bench batch"
         for key in sec:
-            if key != "source":
-                assert any(key in k for k in full), f"traffic.json[{dtype}] names {key!r}, which the built library does not contain"
+            if key not in ("source", "build"):
+                assert any(base(key) in k for k in full), f"traffic.json[{dtype}] names {key!r}, which the built library does not contain"
     nxt = tj.get("next_rows")                 # N3 / N4: the MFCC kernel and the fp64 score GEMM
     if newest >= "r04":
-        assert nxt is not None and f"gpurun_out/{newest}" in nxt["source"]
+        assert nxt is not None and f"gpurun_out/{newest}" in nxt["source"] and nxt.get("build") == want_build
         assert any("mfcc512_kernel" in k for k in nxt) and any("gemm_nt_f64_kernel" in k for k in nxt)
         for key in nxt:
-            if key != "source":
-                assert any(key in k for k in full), f"traffic.json[next_rows] names {key!r}, which the built library does not contain"
+            if key not in ("source", "build"):
+                assert any(base(key) in k for k in full), f"traffic.json[next_rows] names {key!r}, which the built library does not contain"
+        if newest >= "r05":      # the [n, n] score matrix has an entry of its own, with its ratio to the algorithmic bytes
+            big = [v for k, v in nxt.items() if "gemm_nt_f64_kernel<true, 4>" in k]
+            assert big and "ratio_to_algorithmic" in big[0]

@@ -107,9 +107,10 @@ const char* xvec_version(void);
  *   layer 0..4: time_context_layers.{layer}.linear.{weight[out, in*|ctx|], bias[out]}
  *               time_context_layers.{layer}.norm.{weight,bias,running_mean,running_var}[out]
  *               (all four NULL when cfg.batch_norm == 0); eps = BatchNorm1d.eps (1e-5). */
-/* All xvec_load_* calls of a handle must be issued on ONE stream, or be synchronised with each other by the caller: loading
- * layer l also re-packs the bf16 copies of layer l + 1 (whose weights carry layer l's BatchNorm in XVEC_BF16) from the raw
- * weights an earlier xvec_load_tdnn(l + 1) left on ITS stream. */
+/* Layers may be loaded in any order and on different streams: loading layer l also re-packs the bf16 copies of layer l + 1
+ * (whose weights carry layer l's BatchNorm in XVEC_BF16) from what an earlier xvec_load_tdnn(l + 1) left on ITS stream, and
+ * waits for that load's event first.  A forward call must still be ordered behind the loads by the caller (same stream, or a
+ * synchronisation), like any consumer of stream-ordered work. */
 int xvec_load_tdnn(xvec_handle* h, int layer, const float* weight, const float* bias,
                    const float* bn_weight, const float* bn_bias, const float* bn_mean,
                    const float* bn_var, float eps, xvec_stream stream);

@@ -35,9 +35,25 @@ struct GemmArgs {
     const double* colv;
     double* C;
     int64_t lda, ldb, ldc, M, N;
-    int K, tiles_n, n_tiles;
+    int K, tiles_m, tiles_n, n_tiles;
     double cst, scale;
 };
+
+// Tile t of the walk -> (row tile, column tile).  The tiles are walked in 8 x 8 SUPERTILES (bands of eight row tiles, inside a
+// band eight column tiles at a time, row-major inside the supertile): the 64 consecutive tiles an XCD's blocks work on at a time
+// (xcd_remap) then share eight row operands and eight column operands -- 8 MiB at K = 512, the XCD's L2 twice over -- instead
+// of two row operands and ALL column operands (row-major walk, round 4: 950 MB per 4874 x 4874 score matrix for 230 MB of
+// operands and scores).  Bijective for any tiles_m x tiles_n (the last band / the last supertile of a band are narrower).
+__device__ __forceinline__ void tile_rc(int t, int tiles_m, int tiles_n, int& r, int& c) {
+    const int band = t / (8 * tiles_n);
+    const int tb = t - band * 8 * tiles_n;
+    const int h = min(8, tiles_m - 8 * band);
+    const int sc = tb / (8 * h);
+    const int w = min(8, tiles_n - 8 * sc);
+    const int within = tb - sc * 8 * h;
+    r = band * 8 + within / w;
+    c = sc * 8 + within % w;
+}
 
 // two consecutive doubles of row `row` at column k (zero outside the matrix)
 template <bool VEC>
@@ -65,10 +81,12 @@ template <bool VEC, int WT>
 __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(const GemmArgs g) {
     constexpr int kSM = 32 * WT, kSN = 32 * WT;
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    int tile = xcd_remap(blockIdx.x, gridDim.x);          // the column tiles of one row tile share an XCD's L2
+    int tile = xcd_remap(blockIdx.x, gridDim.x);          // 64 consecutive tiles = one supertile share an XCD's L2
     if (tile >= g.n_tiles) return;
-    int64_t m0 = (int64_t)(tile / g.tiles_n) * kSM;
-    int64_t n0 = (int64_t)(tile % g.tiles_n) * kSN;
+    int tr, tc;
+    tile_rc(tile, g.tiles_m, g.tiles_n, tr, tc);
+    int64_t m0 = (int64_t)tr * kSM;
+    int64_t n0 = (int64_t)tc * kSN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1, l15 = lane & 15, l4 = lane >> 4;
     const int piece = tid & 7, row0 = tid >> 3;
@@ -138,8 +156,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(const GemmArgs g) {
     tile += gridDim.x;
     const bool more = tile < g.n_tiles;
     if (more) {
-        m0 = (int64_t)(tile / g.tiles_n) * kSM;
-        n0 = (int64_t)(tile % g.tiles_n) * kSN;
+        tile_rc(tile, g.tiles_m, g.tiles_n, tr, tc);
+        m0 = (int64_t)tr * kSM;
+        n0 = (int64_t)tc * kSN;
         gload(0);
     }
     // ---- epilogue: + rowv[m] + colv[n] + cst, * scale; 16 lanes write 128 contiguous bytes
@@ -238,7 +257,7 @@ int gemm_nt(const double* A, int64_t lda, const double* B, int64_t ldb, int64_t 
     const int ts = small ? 64 : 128;
     const int64_t tm = (M + ts - 1) / ts, tn = (N + ts - 1) / ts;
     if (tm * tn > 0x7fffffff) return sfail(XVEC_ERR_ARG, "score matrix too large for one launch");
-    GemmArgs g{A, B, rowv, colv, C, lda, ldb, ldc, M, N, K, (int)tn, (int)(tm * tn), cst, scale};
+    GemmArgs g{A, B, rowv, colv, C, lda, ldb, ldc, M, N, K, (int)tm, (int)tn, (int)(tm * tn), cst, scale};
     const unsigned grid = (unsigned)std::min<int64_t>(tm * tn, slots);
     const size_t lds = (size_t)2 * (ts + ts) * kSLD * sizeof(double);
     const bool vec = (K % 2 == 0) && (lda % 2 == 0) && (ldb % 2 == 0) && (reinterpret_cast<uintptr_t>(A) % 16 == 0) &&

@@ -82,6 +82,7 @@ struct xvec_handle {
     float* braw[XVEC_NUM_TDNN];        // producing layer's BatchNorm is (re)loaded later
     float* vec16[XVEC_NUM_TDNN];       // bias' | 1 | 0 (n_pad each): epilogue constants of the plain-bf16 kernels
     bool folded[XVEC_NUM_TDNN];        // Wp16 / Wr16 / vec16 of the layer are consistent with the producing layer's BatchNorm
+    hipEvent_t load_evt[XVEC_NUM_TDNN]; // recorded behind a layer's load on the stream that carried it: a re-fold on ANOTHER stream waits for it
     bool tdnn_loaded[XVEC_NUM_TDNN];
     float* affW[3];
     float* affB[3];
@@ -323,6 +324,10 @@ int run_tdnn(xvec_handle* h, int layer, TdnnVariant v, const void* X, int ldx, i
 int refold(xvec_handle* h, int layer, hipStream_t s) {
     if (layer < 0 || layer >= XVEC_NUM_TDNN || !h->tdnn_loaded[layer]) return XVEC_OK;
     if (layer > 0 && !h->tdnn_loaded[layer - 1]) { h->folded[layer] = false; return XVEC_OK; }
+    // the raw weights of this layer and the folded BatchNorm of its producer may have been written by loads on other streams
+    // (ADVICE r04): wait for their events -- no-ops on the stream that recorded them
+    HIP_TRY(hipStreamWaitEvent(s, h->load_evt[layer], 0));
+    if (layer > 0) HIP_TRY(hipStreamWaitEvent(s, h->load_evt[layer - 1], 0));
     const TdnnGeom& g = h->geo16[layer];
     const float* sc = layer > 0 ? h->vec[layer - 1] + h->geo[layer - 1].n_pad : nullptr;
     const float* sh = layer > 0 ? h->vec[layer - 1] + 2 * h->geo[layer - 1].n_pad : nullptr;
@@ -589,6 +594,8 @@ int xvec_create(const xvec_cfg* cfg, xvec_handle** out) {
                            hipHostMallocDefault) == hipSuccess;
     for (int i = 0; i < T_COUNT && ok; ++i)
         ok = hipEventCreate(&h->ev0[i]) == hipSuccess && hipEventCreate(&h->ev1[i]) == hipSuccess;
+    for (int i = 0; i < XVEC_NUM_TDNN && ok; ++i)
+        ok = hipEventCreateWithFlags(&h->load_evt[i], hipEventDisableTiming) == hipSuccess;
     if (!ok) {
         xvec_destroy(h);
         return fail(XVEC_ERR_HIP, "hipEventCreate / hipHostMalloc failed");
@@ -620,6 +627,8 @@ void xvec_destroy(xvec_handle* h) {
         if (h->offs_pinned[i]) (void)hipHostFree(h->offs_pinned[i]);
         if (h->offs_evt[i]) (void)hipEventDestroy(h->offs_evt[i]);
     }
+    for (int i = 0; i < XVEC_NUM_TDNN; ++i)
+        if (h->load_evt[i]) (void)hipEventDestroy(h->load_evt[i]);
     for (int i = 0; i < T_COUNT; ++i) {
         if (h->ev0[i]) (void)hipEventDestroy(h->ev0[i]);
         if (h->ev1[i]) (void)hipEventDestroy(h->ev1[i]);
@@ -654,8 +663,11 @@ int xvec_load_tdnn(xvec_handle* h, int layer, const float* weight, const float* 
                            static_cast<hipStream_t>(stream)));
     HIP_TRY(hipMemcpyAsync(h->braw[layer], bias, (size_t)g.cout * 4, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
     h->tdnn_loaded[layer] = true;
+    HIP_TRY(hipEventRecord(h->load_evt[layer], static_cast<hipStream_t>(stream)));
     if (int rc = refold(h, layer, static_cast<hipStream_t>(stream))) return rc;
     if (int rc = refold(h, layer + 1, static_cast<hipStream_t>(stream))) return rc;
+    // (the re-folds above read what this call wrote: later loads of the neighbours on other streams wait for them too)
+    HIP_TRY(hipEventRecord(h->load_evt[layer], static_cast<hipStream_t>(stream)));
     return XVEC_OK;
 }
 

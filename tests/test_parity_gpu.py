@@ -208,6 +208,21 @@ def test_streamed_extraction_from_host_batches(gpu_model, synth):
         list(extract.stream_x_vectors(gpu_model, iter([batches[0].to(DEV)])))
 
 
+def test_streamed_extraction_from_host_waveforms(gpu_model):
+    """extract.stream_x_vectors(prepare=MfccFrontEnd): host WAVEFORMS in (what the reference's Dataset holds before its
+    per-utterance MFCC call, dataset.py:124-128), the front end on the device between the copy and the path -- the vectors of
+    the direct calls, in order."""
+    import xvector_amd as xa
+    from xvector_amd import extract
+    fe = xa.MfccFrontEnd(device=DEV)
+    g = torch.Generator().manual_seed(8)
+    waves = [0.1 * torch.randn((b, 48000), generator=g) for b in (5, 32, 1, 32)]
+    got = list(extract.stream_x_vectors(gpu_model, iter(waves), depth=2, prepare=fe))
+    assert [v.shape for v in got] == [(b, 512) for b in (5, 32, 1, 32)]
+    for v, w in zip(got, waves):
+        assert torch.equal(v, gpu_model.extract_x_vec(fe(w.to(DEV))).cpu())
+
+
 def test_path_is_graph_capturable(gpu_model, synth):
     """xvec_forward neither synchronises nor allocates: torch.cuda.graph captures the whole path and
     a replay on new input contents reproduces the eager result bit for bit."""

@@ -71,3 +71,38 @@ def test_two_threads_two_handles(sd42, synth, precision):
     assert report[0][0] == 0 and report[1][0] == 0, f"results differ from the single-thread ones: {report}"
     assert b"need at least" in report[0][1]                 # thread 0 still sees its own error ...
     assert report[1][1] == b"", report[1][1]                # ... thread 1, which never failed, sees none
+
+
+def test_layers_loaded_on_different_streams_in_any_order(sd42, synth):
+    """xvec_load_tdnn(l) re-packs layer l + 1's bf16 copies from what an EARLIER load of l + 1 left -- possibly on another stream
+    (ADVICE r04).  Here every layer is loaded on a stream of its own, last layer first, with nothing between the calls; the
+    library orders the re-folds behind the loads they read (per-layer events).  Plain bf16 (the mode that folds) must then give
+    exactly what a model loaded the usual way gives."""
+    import ctypes as C
+    import xvector_amd as xa
+    from xvector_amd import hip
+    from xvector_amd.model import _Engine
+    dev = torch.device(DEV)
+    ref = _model(sd42, "bf16")
+    x = torch.from_numpy(synth.make_mfcc(64, 300, seed=3)).to(DEV)
+    want = ref.extract_x_vec(x).clone()
+    m = xa.XVectorModel(precision="bf16")
+    m.load_state_dict(sd42)
+    m = m.to(DEV).eval()
+    eng = _Engine(m.hparams, dev)
+    streams = [torch.cuda.Stream(DEV) for _ in range(6)]
+    keep = []
+    torch.cuda.synchronize()
+    for i in reversed(range(5)):
+        layer = m.time_context_layers[i]
+        ts = [layer.linear.weight, layer.linear.bias, layer.norm.weight, layer.norm.bias, layer.norm.running_mean, layer.norm.running_var]
+        cs = [t.detach().contiguous() for t in ts]
+        keep += cs
+        hip.check(hip.lib.xvec_load_tdnn(eng.h, i, *[t.data_ptr() for t in cs], layer.norm.eps, streams[i].cuda_stream))
+    for which, lin in ((hip.SEG6, m.segment_layer6), (hip.SEG7, m.segment_layer7), (hip.OUTPUT, m.output)):
+        hip.check(hip.lib.xvec_load_affine(eng.h, which, lin.weight.data_ptr(), lin.bias.data_ptr(), streams[5].cuda_stream))
+    torch.cuda.synchronize()
+    eng.signature = tuple((t.data_ptr(), t._version) for t in m._hot_tensors())
+    m._engines[(dev.type, dev.index)] = eng
+    assert torch.equal(m.extract_x_vec(x), want)
+    assert m._engines[(dev.type, dev.index)] is eng          # the hand-loaded engine is the one that ran

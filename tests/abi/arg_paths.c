@@ -54,6 +54,10 @@ int main(void) {
     EXPECT(xvec_tdnn_pool_layer(0, buf, 1, 32, XVEC_F32, buf, buf, sizeof buf, 0) == XVEC_ERR_ARG);
     EXPECT(xvec_affine(0, XVEC_SEG6, buf, 1, 0, buf, 0) == XVEC_ERR_ARG);
     EXPECT(xvec_set_profiling(0, 1) == XVEC_ERR_ARG);
+    {
+        xvec_ws_layout lay;
+        EXPECT(xvec_workspace_layout(0, 1000, 4, &lay) == XVEC_ERR_ARG);
+    }
     EXPECT(xvec_get_timings(0, buf, &n) == XVEC_ERR_ARG);
     xvec_destroy(0);                                 /* a no-op by contract */
     /* handle-free entry points */

@@ -84,7 +84,10 @@ def _rel(a, b):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("M,N,K", [(1, 1, 1), (3, 5, 7), (128, 128, 16), (129, 127, 33), (200, 300, 512), (64, 1000, 150)])
+# the last two shapes are large enough for the 128 x 128 tiles (>= 768 of them) and their supertile walk, with ragged
+# last bands / supertiles (29 x 28 and 45 x 18 tiles); the others run on the 64 x 64 variant
+@pytest.mark.parametrize("M,N,K", [(1, 1, 1), (3, 5, 7), (128, 128, 16), (129, 127, 33), (200, 300, 512), (64, 1000, 150),
+                                   (3601, 3500, 48), (5700, 2300, 17)])
 def test_gemm_nt_f64_vs_numpy(M, N, K):
     from xvector_amd import scoring
     rng = np.random.default_rng(M * 1000 + N)

@@ -341,19 +341,40 @@ struct FrameSrc {
     __amdgpu_buffer_rsrc_t cur, prev;
     int back;
 };
-__device__ __forceinline__ FrameSrc frame_src(const float* __restrict__ sig, int64_t n_samples, int n_frames,
-                                              int64_t total_frames, int64_t gframe, const MfccDev& d, int used) {
+// (utterance b, frame f of the utterance) of global frame g.  Round 5: ONE magic division per wave and tile -- the wave's four
+// frames of a tile are consecutive, the other three are stepped from the first (frame_step_bf) -- and everything below in 32-bit
+// scalar arithmetic where the launch allows it: in-kernel stamps put 17 % of a wave's time at the head of a pair, in the scalar
+// work of two descriptors built from scratch (154 scalar instructions and 42 wait states per pair).
+struct FramePos {
+    unsigned b, f;
+};
+__device__ __forceinline__ FramePos frame_pos(int64_t gframe, int64_t total_frames, int n_frames, const MfccDev& d) {
+    const unsigned gf = gframe < total_frames ? (unsigned)gframe : 0u;     // the launcher keeps total_frames below 2^31
+    // (a 32-bit division by a run-time divisor is ~30 scalar instructions; by the launch's magic number a multiply-high and a shift)
+    FramePos p;
+    p.b = (unsigned)(((unsigned long long)gf * d.fr_magic) >> (31 + d.fr_shift));
+    p.f = gf - p.b * (unsigned)n_frames;
+    return p;
+}
+__device__ __forceinline__ FramePos frame_step_bf(FramePos p, int n_frames) {
+    p.f += 1;
+    if (p.f >= (unsigned)n_frames) {
+        p.f = 0;
+        p.b += 1;
+    }
+    return p;
+}
+// (n_samples < 2^30 on this path -- xvec_mfcc sends longer signals to the generic kernel -- so a frame's position inside its
+//  signal is 32-bit scalar arithmetic; only the utterance's base is a 64-bit product)
+__device__ __forceinline__ FrameSrc frame_src(const float* __restrict__ sig, int n_samples, int64_t total_frames,
+                                              int64_t gframe, FramePos fp, const MfccDev& d, int used) {
     const bool live = gframe < total_frames;
-    const unsigned gf = live ? (unsigned)gframe : 0u;          // the launcher keeps total_frames below 2^31
-    // (a 32-bit division by a run-time divisor is ~30 scalar instructions, four times per wave and tile: 270 SALU instructions
-    //  per wave and tile in round 3's counters; by the launch's magic number it is a multiply-high and a shift)
-    const unsigned b = (unsigned)(((unsigned long long)gf * d.fr_magic) >> (31 + d.fr_shift));
-    const int64_t start = (int64_t)(gf - b * (unsigned)n_frames) * d.frame_step;
-    const int64_t left = n_samples - start;                    // samples from `start` to the end of the signal
-    const int lim = live && left > 0 ? (int)(left < used ? left : used) : 0;   // (a frame step longer than the frame can start past the end)
+    const int start = (int)fp.f * d.frame_step;
+    const int left = n_samples - start;                        // samples from `start` to the end of the signal
+    const int lim = live && left > 0 ? (left < used ? left : used) : 0;   // (a frame step longer than the frame can start past the end)
     FrameSrc f;
-    f.back = start > 0 ? 1 : 0;                                // x[start - 1] exists
-    const unsigned long long base = reinterpret_cast<unsigned long long>(sig + (int64_t)b * n_samples + start - f.back);
+    f.back = fp.f > 0 ? 1 : 0;                                 // x[start - 1] exists
+    const unsigned long long base = reinterpret_cast<unsigned long long>(sig + (int64_t)fp.b * n_samples + (start - f.back));
     const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)base);
     const unsigned bhi = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32));
     void* q = reinterpret_cast<void*>(((unsigned long long)bhi << 32) | blo);
@@ -408,19 +429,37 @@ __global__ __launch_bounds__(256, 4) void mfcc512_kernel(const float* __restrict
     // the previous pair / the previous tile's matrix products) measured the same, interleaved on one box: with four
     // waves per SIMD the memory latency is already covered, the kernel is issue-bound (VALU 50 %, LDS array 54 % busy).
     c32 cur[8], prev[8];
+    // Sample n = 64 a + lane of a frame sits at byte (n + back) * 4 of its descriptor (x[n-1] four bytes lower): ONE lane offset
+    // per frame (4 * (lane + back)) and the instruction's immediate offset do that.  The loads are asm so that the immediates
+    // stay immediates (given the offsets as expressions hipcc built 32 offset registers per pair with 48 vector instructions --
+    // a fifth of the pair's vector work); hipcc does not see asm loads, so the wait for them is written out behind the request.
+    const int l4 = lane * 4;
+    const int n32 = (int)n_samples;
+#define MF_LD(dst_, rs_, vo_, imm_) asm volatile("buffer_load_dword %0, %1, %2, 0 offen offset:%3" : "=v"(dst_) : "v"(vo_), "s"(rs_), "i"(imm_) : "memory");
+#define MF_LOAD_FRAME(S_, H_)                                                                                  \
+    {                                                                                                          \
+        const int vc_ = l4 + 4 * S_.back, vp_ = vc_ - 4;   /* vp_ = -4 in lane 0 at a signal's start: out of range, 0 */ \
+        asm volatile("s_nop 4" ::: "memory");   /* descriptor words may come out of v_readfirstlane: 5 wait states before a load reads them (hipcc pads nothing in front of asm) */ \
+        MF_LD(cur[0].H_, S_.cur, vc_, 0) MF_LD(cur[1].H_, S_.cur, vc_, 256) MF_LD(cur[2].H_, S_.cur, vc_, 512) MF_LD(cur[3].H_, S_.cur, vc_, 768) \
+        MF_LD(cur[4].H_, S_.cur, vc_, 1024) MF_LD(cur[5].H_, S_.cur, vc_, 1280) MF_LD(cur[6].H_, S_.cur, vc_, 1536) MF_LD(cur[7].H_, S_.cur, vc_, 1792) \
+        MF_LD(prev[0].H_, S_.prev, vp_, 0) MF_LD(prev[1].H_, S_.prev, vp_, 256) MF_LD(prev[2].H_, S_.prev, vp_, 512) MF_LD(prev[3].H_, S_.prev, vp_, 768) \
+        MF_LD(prev[4].H_, S_.prev, vp_, 1024) MF_LD(prev[5].H_, S_.prev, vp_, 1280) MF_LD(prev[6].H_, S_.prev, vp_, 1536) MF_LD(prev[7].H_, S_.prev, vp_, 1792) \
+    }
 #define MF_REQUEST(fa_)                                                                                        \
     {                                                                                                          \
-        const FrameSrc sa = frame_src(sig, n_samples, n_frames, total_frames, (fa_), d, used);                 \
-        const FrameSrc sb = frame_src(sig, n_samples, n_frames, total_frames, (fa_) + 1, d, used);             \
-        _Pragma("unroll") for (int a = 0; a < 8; ++a) {                                                        \
-            const int oa = (lane + 64 * a + sa.back) * 4, ob = (lane + 64 * a + sb.back) * 4;                  \
-            cur[a] = c32{ldf(sa.cur, oa), ldf(sb.cur, ob)};                                                    \
-            prev[a] = c32{ldf(sa.prev, oa - 4), ldf(sb.prev, ob - 4)}; /* -4 at a signal's start: out of range, 0 */ \
-        }                                                                                                      \
+        const FrameSrc sa = frame_src(sig, n32, total_frames, (fa_), fpos, d, used);                     \
+        fpos = frame_step_bf(fpos, n_frames);                                                                  \
+        const FrameSrc sb = frame_src(sig, n32, total_frames, (fa_) + 1, fpos, d, used);                 \
+        fpos = frame_step_bf(fpos, n_frames);                                                                  \
+        MF_LOAD_FRAME(sa, x)                                                                                   \
+        MF_LOAD_FRAME(sb, y)                                                                                   \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
     }
     int par = 0;
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, par ^= 1) {
         // ---- FFT of this wave's two pairs of frames, power spectra into P
+        FramePos fpos = frame_pos((int64_t)tile * kTile + 4 * wave, total_frames, n_frames, d);     // the wave's first frame of the tile
 #pragma unroll 1
         for (int pp = 0; pp < 2; ++pp) {
             const int r0 = 4 * wave + 2 * pp;                       // rows of the pair in the tile
@@ -536,7 +575,6 @@ __global__ __launch_bounds__(256, 4) void mfcc512_kernel(const float* __restrict
         __syncthreads();
         // ---- DCT-II x lifter: waves 0 and 1, one tile of 16 cepstra each; the others go on to the next tile
         if (wave < 2) {
-            // the DCT fragments (2 KiB per wave, L1/L2 hits) are fetched here rather than held through the FFTs
             f32x4v db[2];
             db[0] = reinterpret_cast<const f32x4v*>(d.f_dct)[(wave * 2 + 0) * 64 + lane];
             db[1] = reinterpret_cast<const f32x4v*>(d.f_dct)[(wave * 2 + 1) * 64 + lane];
@@ -563,6 +601,8 @@ __global__ __launch_bounds__(256, 4) void mfcc512_kernel(const float* __restrict
 }
 
 #undef MF_REQUEST
+#undef MF_LOAD_FRAME
+#undef MF_LD
 
 }  // namespace fft512
 
@@ -771,7 +811,7 @@ int xvec_mfcc(xvec_mfcc_plan* p, const float* signal, int32_t B, int64_t n_sampl
     if (B < 1 || B > 65535 || n_samples < 1) return mfail(XVEC_ERR_ARG, "need 1 <= B <= 65535 and n_samples >= 1");
     const int n_frames = xvec_mfcc_frames(p, n_samples);
     const int64_t total_frames = (int64_t)B * n_frames;
-    if (p->fast && total_frames < (int64_t(1) << 31) - fft512::kTile) {
+    if (p->fast && total_frames < (int64_t(1) << 31) - fft512::kTile && n_samples < (int64_t(1) << 30)) {
         const int n_tiles = (int)((total_frames + fft512::kTile - 1) / fft512::kTile);
         const int grid = std::min(n_tiles, 4 * p->num_cu);
         MfccDev dv = p->dev;

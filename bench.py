@@ -97,6 +97,24 @@ def self_launch(n, argv, port=0):
         return child.wait()
 
 
+def attribution(marks, collective, world):
+    """config.per_rank_compute_s / config.all_gather_ms of a --gpus N line: every rank's own extraction time and the time of the
+    one collective (which includes waiting for the slowest rank), gathered over the group AFTER the timed region, so that
+    a scaling loss can be put on imbalance, on the exchange or on neither.  marks: extract.Marks with three marks."""
+    import torch.distributed as dist
+    spans = marks.spans()
+    mine = {"compute_s": spans[0], "all_gather_s": spans[1] if len(spans) > 1 else 0.0}
+    rows = [mine] * world
+    if collective:
+        rows = [None] * world
+        dist.all_gather_object(rows, mine)
+    comp = [r["compute_s"] for r in rows]
+    gath = [r["all_gather_s"] for r in rows]
+    return {"per_rank_compute_s": {"min": round(min(comp), 6), "max": round(max(comp), 6),
+                                   "ranks": [round(c, 6) for c in comp]},
+            "all_gather_ms": {"min": round(min(gath) * 1e3, 4), "max": round(max(gath) * 1e3, 4)}}
+
+
 def dry_run(args, world, rank):
     """The N>1 control flow on CPU (gloo): barriers, K steps, the all-gather of [K*B,512] per rank (or the sharded
     job), max-over-ranks timing, one JSON line from rank 0.  No GPU, no library, no measurement."""
@@ -122,22 +140,27 @@ def dry_run(args, world, rank):
     fake = lambda x: torch.full((x.shape[0], 512), float(rank))      # noqa: E731
     if collective:
         dist.barrier()
+    marks = extract.Marks()
     t0 = time.perf_counter()
     if args.workload == "job":
         full = extract.extract_sharded(fake, lambda lo, hi: torch.zeros((hi - lo, 1, 1)), args.utterances,
-                                       batch_size=B, force_collective=args.force_collective)
+                                       batch_size=B, force_collective=args.force_collective, marks=marks)
         assert full.shape == (args.utterances, 512)
         n_done = args.utterances
     else:
+        marks.mark()
         emb = torch.cat([fake(torch.zeros((B, 1, 1))) for _ in range(K)])
+        marks.mark()
         if collective:
             gathered = torch.empty((world * K * B, 512))
             dist.all_gather_into_tensor(gathered, emb)
             assert all(float(gathered[r * K * B, 0]) == r for r in range(world))
+        marks.mark()
         n_done = world * K * B
     if collective:
         dist.barrier()
     dt = time.perf_counter() - t0
+    attr = attribution(marks, collective, world)
     if collective:
         t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -149,7 +172,7 @@ def dry_run(args, world, rank):
             "higher_is_better": True, "scaling": "strong" if args.workload == "job" else "weak", "vs_baseline": None,
             "dtype": "none", "data": "dry-run",
             "config": {"workload": f"DRY RUN of the launch / collective path on CPU (gloo), {args.workload}; no GPU work",
-                       "batch_per_gpu": B, "sharding": f"utterance-sharded x{world}"}}), flush=True)
+                       "batch_per_gpu": B, "sharding": f"utterance-sharded x{world}", **attr}}), flush=True)
     if collective:
         dist.destroy_process_group()
     return 0
@@ -272,7 +295,7 @@ def main():
         return xa.extract.extract_sharded(
             model.extract_x_vec,
             lambda lo, hi: torch.randn((hi - lo, T, 24), generator=gen, device=dev, dtype=torch.float32),
-            args.utterances, batch_size=B, force_collective=args.force_collective)
+            args.utterances, batch_size=B, force_collective=args.force_collective, marks=marks)
 
     def barrier():
         if collective:
@@ -300,15 +323,19 @@ def main():
     torch.cuda.synchronize(dev)
     barrier()
     torch.cuda.synchronize(dev)
+    marks = xa.extract.Marks(dev)          # events on the launch stream: a rank's own work | the collective (no host sync between)
     t0 = time.perf_counter()
     if n_local is not None:
         full = job()
         assert full.shape == (args.utterances, 512)
     else:
+        marks.mark()
         for k in range(K):
             step(k)
+        marks.mark()
         if collective:
             dist.all_gather_into_tensor(gathered, emb)
+        marks.mark()
     torch.cuda.synchronize(dev)
     barrier()
     torch.cuda.synchronize(dev)
@@ -317,6 +344,7 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    attr = attribution(marks, collective, world)
 
     # ---- single-GPU extras, reported beside the headline and never as `value`.  Skipped for N>1 (they
     # are per-GPU figures, and a graph capture beside a live RCCL communicator is not worth risking
@@ -411,7 +439,6 @@ def main():
             "bf16_path_flop_frac_of_peak": round(K2 * B / d16 * total_flops(T) / BF16_MFMA_PEAK, 4),
             "bf16_path_hbm_frac_algorithmic": round(K2 * B / d16 * BYTES_PER_UTT * T / 300.0 * 0.5 / HBM_PEAK, 4),
             "bf16_per_kernel_ms": {n: round(v, 4) for n, v in ms16.items()}})
-        del m16
         # bf16x3: fp32 values as two bf16 planes, three bf16 products -- the same 1e-4 bar as the headline
         m3 = xa.XVectorModel(precision="bf16x3")
         m3.load_state_dict(sd)
@@ -447,6 +474,20 @@ def main():
             "ragged_ms_per_step": round(dr / K3 * 1e3, 4), "ragged_valid_frames_per_batch": int(lens_np.sum()),
             "ragged_workload": f"configs[2]: batch={B} utterances of 200-1000 frames (numpy default_rng(1234)), zero-padded "
                                f"to {Tr} with a lengths mask, fp32"})
+        # configs[2] x configs[4]: the same ragged batch through the bf16 path
+        preroll(lambda: m16.extract_x_vec(xr, lengths=ll), min(args.preroll, 0.25))
+        for _ in range(3):
+            m16.extract_x_vec(xr, lengths=ll)
+        torch.cuda.synchronize(dev)
+        t4 = time.perf_counter()
+        for _ in range(K3):
+            m16.extract_x_vec(xr, lengths=ll)
+        torch.cuda.synchronize(dev)
+        dr16 = time.perf_counter() - t4
+        secondary.update({"ragged_bf16_utt_per_s": round(K3 * B / dr16, 1),
+                          "ragged_bf16_valid_frames_per_s": round(K3 * int(lens_np.sum()) / dr16, 1),
+                          "ragged_bf16_ms_per_step": round(dr16 / K3 * 1e3, 4)})
+        del m16
 
     def next_row_legs():
         """The rows either side of the path, short timed loops, never `value`: waveform -> MFCC ->
@@ -471,7 +512,6 @@ def main():
         m16w.load_state_dict(sd)
         m16w = m16w.to(dev).eval()
         secondary["wave_bf16_utt_per_s"] = round(B / timed(lambda: m16w.extract_x_vec(fe2(wv)), K4), 1)
-        del m16w
         # ... and with the boundary handing over HOST waveforms (the reference's producer is host-side, dataset.py:124-128):
         # pinned fp32 [B, 48000] batches through the product's overlapped pipeline (extract.stream_x_vectors: H2D on a side
         # stream, MFCC + path on the compute stream, results to pinned host buffers); 49 MB per batch over PCIe
@@ -485,6 +525,23 @@ def main():
             pass
         torch.cuda.synchronize(dev)
         secondary["wave_pcie_inclusive_utt_per_s"] = round(n_w * B / (time.perf_counter() - t_w), 1)
+        # the bf16 path behind the same boundary: fp32 samples (49 MB per batch: the link, not the GPU, sets the rate) and
+        # 16-bit PCM as scipy.io.wavfile.read yields it (dataset.py:125; xvec_mfcc_i16 converts in the kernel: half the bytes)
+        pcm_host = (wv * 3.0e4).clamp(-32768, 32767).to(torch.int16).cpu().pin_memory()
+        for key, host in (("wave_bf16_pcie_inclusive_f32_samples_utt_per_s", wv_host), ("wave_bf16_pcie_inclusive_utt_per_s", pcm_host)):
+            n_b = 60
+            for _ in xa.extract.stream_x_vectors(m16w, (host for _ in range(n_b)), prepare=fe2):
+                pass
+            torch.cuda.synchronize(dev)
+            t_b = time.perf_counter()
+            for _ in xa.extract.stream_x_vectors(m16w, (host for _ in range(n_b)), prepare=fe2):
+                pass
+            torch.cuda.synchronize(dev)
+            secondary[key] = round(n_b * B / (time.perf_counter() - t_b), 1)
+        secondary["wave_bf16_pcie_inclusive_input"] = "int16 PCM [B, 48000] in pinned host memory (24.6 MB per batch), scale 1"
+        pcm_dev = pcm_host.to(dev)
+        secondary["mfcc_i16_us_per_batch"] = round(timed(lambda: fe2(pcm_dev), 50, 0.05) * 1e6, 2)
+        del m16w
         secondary["mfcc_us_per_batch"] = round(timed(lambda: fe2(wv), 50, 0.05) * 1e6, 2)
         secondary["mfcc_algorithmic_gb_per_s"] = round(B * (48000 * 4 + 299 * 24 * 4) / (secondary["mfcc_us_per_batch"] * 1e-6) / 1e9, 1)
         n_sc = 4874                                                    # VoxCeleb1 test set (plda_score_stat.py:19-20: every x-vector against every other)
@@ -492,7 +549,12 @@ def main():
         scorer = xa.scoring.PldaScorer(mean, F, Sigma, device=dev)
         xs = torch.randn((n_sc, 512), generator=gen, device=dev, dtype=torch.float32).double() + torch.from_numpy(mean).to(dev)
         secondary["plda_score_ms_n4874"] = round(timed(lambda: scorer.score(xs), 10, 0.05) * 1e3, 4)
-        secondary["plda_gemm_tflops_f64"] = round(2.0 * n_sc * n_sc * 512 / (secondary["plda_score_ms_n4874"] * 1e-3) / 1e12, 1)
+        secondary["plda_score_form"] = (f"self-score of {n_sc} x-vectors, low-rank form (rank {scorer.rank} of 512): y = (x - mean) L, "
+                                        "[y W | row dots], upper triangle of y W y' mirrored")
+        dense = xa.scoring.PldaScorer(mean, F, Sigma, device=dev, lowrank=False)
+        secondary["plda_dense_score_ms_n4874"] = round(timed(lambda: dense.score(xs), 10, 0.05) * 1e3, 4)
+        # fp64 rate of the dense form's [n, n] launch work actually done: upper triangle of tiles + the [n, 1024] prelude product
+        secondary["plda_dense_tflops_f64"] = round((n_sc * n_sc * 512.0 + 2.0 * n_sc * 1024 * 512) / (secondary["plda_dense_score_ms_n4874"] * 1e-3) / 1e12, 1)
 
     def job_leg():
         """configs[3] at its own size on this one GPU (the N = 1 anchor of the scaling curve): 100 000 utterances generated
@@ -505,6 +567,19 @@ def main():
         torch.cuda.synchronize(dev)
         assert full.shape == (n_job, 512)
         secondary["job100k_embeddings_per_s"] = round(n_job / (time.perf_counter() - t_j), 1)
+        # configs[3] x configs[4]: the same job through the bf16 path
+        m16j = xa.XVectorModel(precision="bf16")
+        m16j.load_state_dict(sd)
+        m16j = m16j.to(dev).eval()
+        preroll(lambda: m16j.extract_x_vec(x), min(args.preroll, 0.25))
+        torch.cuda.synchronize(dev)
+        t_j = time.perf_counter()
+        full = xa.extract.extract_sharded(
+            m16j.extract_x_vec, lambda lo, hi: torch.randn((hi - lo, T, 24), generator=gen, device=dev, dtype=torch.float32),
+            n_job, batch_size=B)
+        torch.cuda.synchronize(dev)
+        assert full.shape == (n_job, 512)
+        secondary["job100k_bf16_embeddings_per_s"] = round(n_job / (time.perf_counter() - t_j), 1)
 
     if (world == 1 and not args.force_collective and not args.no_secondary and args.workload == "fixed"
             and args.dtype == "fp32"):
@@ -583,7 +658,7 @@ def main():
                        "preroll_s": args.preroll if n_local is None else 0.0,
                        "sharding": f"utterance-sharded x{world}"
                        + (", one all-gather of [K*B,512] fp32 in the timed region" if collective else ""),
-                       **secondary},
+                       **attr, **secondary},
             "roofline": {
                 "bound": "mfma", "kernel": dom_kernel,
                 "achieved": round(achieved, 2), "peak": peak / 1e12, "unit": "TFLOP/s",

@@ -227,6 +227,11 @@ int32_t xvec_mfcc_frames(const xvec_mfcc_plan* plan, int64_t n_samples);
 /* signal[B, n_samples] fp32 (device) -> out[B, frames, numcep] fp32 (device) */
 int xvec_mfcc(xvec_mfcc_plan* plan, const float* signal, int32_t B, int64_t n_samples, float* out,
               xvec_stream stream);
+/* The same for 16-bit PCM as scipy.io.wavfile.read yields it (reference dataset.py:125): every sample enters as
+ * (float)s * scale -- one fp32 rounding, exactly what xvec_mfcc is given when the caller converts first, so the two agree bit
+ * for bit; half the bytes over PCIe and out of HBM.  scale = 1 keeps the raw PCM range the reference's call sees. */
+int xvec_mfcc_i16(xvec_mfcc_plan* plan, const int16_t* signal, float scale, int32_t B, int64_t n_samples, float* out,
+                  xvec_stream stream);
 
 #ifdef __cplusplus
 }

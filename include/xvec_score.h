@@ -47,6 +47,17 @@ int xvec_plda_score(const double* enroll, int64_t n_enroll, const double* test, 
                     double plda_cst, double scaling_factor, double* scores, void* workspace,
                     size_t workspace_bytes, xvec_stream stream);
 
+/* The same scores through the model's low-rank structure: with tot = F F' + Sigma, L = tot^-1 F [dim, rank], G = F' L,
+ * W = (I - G^2)^-1, Z = W G the matrices above are Phi = -L Z L' and Psi = L W L' exactly, so with y = (x - mean) L
+ *   scores[i,j] = scaling * ( -0.5 y_i Z y_i' - 0.5 y_j Z y_j' + (y_i W) y_j' + plda_cst )
+ * and the [n_enroll, n_test] product runs over rank instead of dim (the reference trains rank_f = 50 .. 200 on 512-d
+ * x-vectors, main.py:293-308).  l_t = L^T [rank, dim]; wz_t = [ W^T ; (-Z)^T ] stacked [2 rank, rank]; both row-major,
+ * derived once per model by the host (scoring.plda_lowrank).  Same workspace as xvec_plda_score; test == NULL as above. */
+int xvec_plda_score_lowrank(const double* enroll, int64_t n_enroll, const double* test, int64_t n_test,
+                            int32_t dim, int32_t rank, const double* mean, const double* l_t, const double* wz_t,
+                            double plda_cst, double scaling_factor, double* scores, void* workspace,
+                            size_t workspace_bytes, xvec_stream stream);
+
 /* Cosine scoring: scores[i,j] = <enroll_i, test_j> / (|enroll_i| |test_j|).  test == NULL as above. */
 int xvec_cosine_score(const double* enroll, int64_t n_enroll, const double* test, int64_t n_test,
                       int32_t dim, double* scores, void* workspace, size_t workspace_bytes,

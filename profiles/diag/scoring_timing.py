@@ -11,7 +11,8 @@ import plda_oracle as po          # model generator + CPU timing only
 dev = "cuda:0"
 dim = 512
 mean, F, Sigma = po.make_plda(dim, 200, seed=21)
-scorer = scoring.PldaScorer(mean, F, Sigma)
+scorer = scoring.PldaScorer(mean, F, Sigma)                      # low-rank form (rank 200 < 512)
+dense = scoring.PldaScorer(mean, F, Sigma, lowrank=False)        # the package's dense Phi / Psi products
 
 def ev_time(fn, n=20):
     for _ in range(3): fn()
@@ -27,7 +28,12 @@ for n in (4874, 16384):
     x = torch.randn((n, dim), device=dev, dtype=torch.float64) + torch.from_numpy(mean).to(dev)
     ms = ev_time(lambda: scorer.score(x))
     fl = 2.0 * n * n * dim + 2 * 2.0 * n * dim * dim
-    print(f"plda self-score N={n}: {ms:.3f} ms  {fl / ms / 1e9:.1f} TFLOP/s fp64 (whole call), {n * n / ms / 1e6:.1f} G scores/s")
+    print(f"plda self-score N={n}, low-rank: {ms:.3f} ms  {n * n / ms / 1e6:.1f} G scores/s")
+    ms = ev_time(lambda: dense.score(x))
+    print(f"plda self-score N={n}, dense: {ms:.3f} ms  {fl / 2 / ms / 1e9:.1f} TFLOP/s fp64 (upper triangle), {n * n / ms / 1e6:.1f} G scores/s")
+    y = x[: n // 2].contiguous(); z = x[n // 2:].contiguous()
+    ms = ev_time(lambda: scorer.score(y, z))
+    print(f"plda two sets {n // 2} x {n - n // 2}, low-rank: {ms:.3f} ms;  dense: {ev_time(lambda: dense.score(y, z)):.3f} ms")
     a = x.contiguous()
     ms = ev_time(lambda: scoring.gemm_nt(a, a))
     print(f"   gemm_nt alone: {ms:.3f} ms  {2.0 * n * n * dim / ms / 1e9:.1f} TFLOP/s")

@@ -46,6 +46,7 @@ struct MfccDev {
     // g < 2^31 (fr_magic = ceil(2^(31 + fr_shift) / n_frames), fr_shift = ceil(log2 n_frames); set per launch by xvec_mfcc)
     unsigned fr_magic;
     int fr_shift;
+    float in_scale;         // 16-bit PCM input (xvec_mfcc_i16): sample = (float)s * in_scale, one fp32 rounding (set per launch)
 };
 
 __device__ __forceinline__ unsigned bitrev(unsigned v, int bits) { return __brev(v) >> (32 - bits); }
@@ -76,9 +77,13 @@ constexpr int kWavesPerBlock = kThreads / 64;
 // L2N: log2(nfft) fixed at compile time (9: the reference's nfft = 512), or 0 = taken from `d`.  With
 // constant trip counts the sample loads of a frame, the two butterfly groups of a pass and the
 // bins of the split are issued together instead of one LDS / memory round trip at a time.
-template <int L2N>
-__global__ __launch_bounds__(kThreads) void mfcc_kernel(const float* __restrict__ sig, int64_t n_samples,
+// S: sample type, float or int16_t (16-bit PCM as scipy.io.wavfile.read yields it, reference dataset.py:125: every sample is
+// (float)s * d.in_scale, exactly what the float path is given when the caller converts on the host).
+template <int L2N, typename S>
+__global__ __launch_bounds__(kThreads) void mfcc_kernel(const S* __restrict__ sig, int64_t n_samples,
                                                         int n_frames, MfccDev d, float* __restrict__ out) {
+    constexpr bool I16 = sizeof(S) == 2;
+    auto smp = [&](const S* p_, int64_t i_) -> float { return I16 ? (float)p_[i_] * d.in_scale : (float)p_[i_]; };
     const int log2n = L2N ? L2N : d.log2n;
     const int nfft = L2N ? (1 << L2N) : d.nfft;
     extern __shared__ float lds[];
@@ -100,7 +105,7 @@ __global__ __launch_bounds__(kThreads) void mfcc_kernel(const float* __restrict_
     const int fa = 2 * (blockIdx.x * kWavesPerBlock + wave), b = blockIdx.y;
     if (fa >= n_frames) return;                               // whole wave leaves together (no later block barrier)
     const bool has_b = fa + 1 < n_frames;
-    const float* s = sig + (int64_t)b * n_samples;
+    const S* s = sig + (int64_t)b * n_samples;
     const int64_t start = (int64_t)fa * d.frame_step;
     const int used = d.frame_len < nfft ? d.frame_len : nfft;   // rfft(frame, nfft) truncates long frames
 
@@ -110,8 +115,8 @@ __global__ __launch_bounds__(kThreads) void mfcc_kernel(const float* __restrict_
         float va = 0.f, vb = 0.f;
         if (n < used) {
             const int64_t ga = start + n, gb = ga + d.frame_step;
-            if (ga < n_samples) va = (ga == 0) ? s[0] : s[ga] - d.preemph * s[ga - 1];
-            if (has_b && gb < n_samples) vb = s[gb] - d.preemph * s[gb - 1];
+            if (ga < n_samples) va = (ga == 0) ? smp(s, 0) : smp(s, ga) - d.preemph * smp(s, ga - 1);
+            if (has_b && gb < n_samples) vb = smp(s, gb) - d.preemph * smp(s, gb - 1);
         }
         z[zpos((int)bitrev((unsigned)n, log2n))] = make_float2(va, vb);
     }
@@ -229,6 +234,19 @@ __global__ __launch_bounds__(kThreads) void mfcc_kernel(const float* __restrict_
 //    [16 x 32] x DCTL^T[32 x 32].  The B fragments are packed per lane on the host and stay in registers:
 //    blocks are persistent (four per CU) and walk the tiles with a grid stride.
 namespace fft512 {
+
+#ifdef XVEC_MFKNOCK
+// Timing-only knock-outs of mfcc512_kernel (-DXVEC_MFKNOCK=mask; results are garbage):
+//   bit 0: no third transpose, the split reads its operands from the lane's own registers (bound of an in-register split)
+//   bit 1: the DCT fragments are not fetched per tile      bit 2: no tile tail at all (filterbank, log, DCT, two barriers)
+#define MF_KNOCK_T3 ((XVEC_MFKNOCK & 1) != 0)
+#define MF_KNOCK_DCTLD ((XVEC_MFKNOCK & 2) != 0)
+#define MF_KNOCK_TAIL ((XVEC_MFKNOCK & 4) != 0)
+#else
+#define MF_KNOCK_T3 false
+#define MF_KNOCK_DCTLD false
+#define MF_KNOCK_TAIL false
+#endif
 
 constexpr int kTile = 16;                   // frames per block pass
 constexpr int kEx = 576;                    // complex slots of a wave's exchange region (8 x 72)
@@ -366,7 +384,8 @@ __device__ __forceinline__ FramePos frame_step_bf(FramePos p, int n_frames) {
 }
 // (n_samples < 2^30 on this path -- xvec_mfcc sends longer signals to the generic kernel -- so a frame's position inside its
 //  signal is 32-bit scalar arithmetic; only the utterance's base is a 64-bit product)
-__device__ __forceinline__ FrameSrc frame_src(const float* __restrict__ sig, int n_samples, int64_t total_frames,
+template <int ES>      // bytes per sample: 4 (fp32) or 2 (16-bit PCM)
+__device__ __forceinline__ FrameSrc frame_src(const void* __restrict__ sig, int n_samples, int64_t total_frames,
                                               int64_t gframe, FramePos fp, const MfccDev& d, int used) {
     const bool live = gframe < total_frames;
     const int start = (int)fp.f * d.frame_step;
@@ -374,11 +393,11 @@ __device__ __forceinline__ FrameSrc frame_src(const float* __restrict__ sig, int
     const int lim = live && left > 0 ? (left < used ? left : used) : 0;   // (a frame step longer than the frame can start past the end)
     FrameSrc f;
     f.back = fp.f > 0 ? 1 : 0;                                 // x[start - 1] exists
-    const unsigned long long base = reinterpret_cast<unsigned long long>(sig + (int64_t)fp.b * n_samples + (start - f.back));
+    const unsigned long long base = reinterpret_cast<unsigned long long>(sig) + ((int64_t)fp.b * n_samples + (start - f.back)) * ES;
     const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)base);
     const unsigned bhi = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32));
     void* q = reinterpret_cast<void*>(((unsigned long long)bhi << 32) | blo);
-    const int n_cur = (lim + f.back) * 4, n_prev = n_cur >= 4 ? n_cur - 4 : 0;
+    const int n_cur = (lim + f.back) * ES, n_prev = n_cur >= ES ? n_cur - ES : 0;
     f.cur = __builtin_amdgcn_make_buffer_rsrc(q, (short)0, __builtin_amdgcn_readfirstlane(n_cur), 0x00020000);
     f.prev = __builtin_amdgcn_make_buffer_rsrc(q, (short)0, __builtin_amdgcn_readfirstlane(n_prev), 0x00020000);
     return f;
@@ -387,9 +406,11 @@ __device__ __forceinline__ float ldf(__amdgpu_buffer_rsrc_t r, int off) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
 }
 
-__global__ __launch_bounds__(256, 4) void mfcc512_kernel(const float* __restrict__ sig, int64_t n_samples, int n_frames,
+template <bool I16>     // samples: fp32, or 16-bit PCM converted on the way in ((float)s * d.in_scale)
+__global__ __launch_bounds__(256, 4) void mfcc512_kernel(const void* __restrict__ sig, int64_t n_samples, int n_frames,
                                                          int64_t total_frames, int n_tiles, MfccDev d,
                                                          float* __restrict__ out) {
+    constexpr int ES = I16 ? 2 : 4;
     __shared__ __attribute__((aligned(16))) float smem[kLdsFloats];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -428,33 +449,54 @@ __global__ __launch_bounds__(256, 4) void mfcc512_kernel(const float* __restrict
     // raw samples of a pair of frames (x[n] and x[n-1] of both).  Requesting them one pair ahead (during the split of
     // the previous pair / the previous tile's matrix products) measured the same, interleaved on one box: with four
     // waves per SIMD the memory latency is already covered, the kernel is issue-bound (VALU 50 %, LDS array 54 % busy).
-    c32 cur[8], prev[8];
-    // Sample n = 64 a + lane of a frame sits at byte (n + back) * 4 of its descriptor (x[n-1] four bytes lower): ONE lane offset
-    // per frame (4 * (lane + back)) and the instruction's immediate offset do that.  The loads are asm so that the immediates
+    // (every load writes a SCALAR of its own: an asm output that is one half of a register pair goes through a temporary and a
+    //  copy, which hipcc places right behind the load -- before the data has landed)
+    float cur_a[8], cur_b[8], prev_a[8], prev_b[8];                 // x[n] and x[n-1] of frame A (real part) and frame B (imaginary part)
+    // Sample n = 64 a + lane of a frame sits at byte (n + back) * ES of its descriptor (x[n-1] one sample lower): ONE lane offset
+    // per frame (ES * (lane + back)) and the instruction's immediate offset do that.  The loads are asm so that the immediates
     // stay immediates (given the offsets as expressions hipcc built 32 offset registers per pair with 48 vector instructions --
     // a fifth of the pair's vector work); hipcc does not see asm loads, so the wait for them is written out behind the request.
-    const int l4 = lane * 4;
+    // (the lane offset of x[n-1] is -ES in lane 0 at a signal's start: added to the immediates 64 a ES it addresses x[64a - 1]
+    //  for a >= 1 and, as an unsigned offset, lands far outside the descriptor's range for a = 0, which reads as 0 -- the
+    //  hardware sums lane offset and immediate BEFORE the range check; tests/test_mfcc.py, test_first_frame_previous_samples,
+    //  pins exactly these samples)
+    const int lES = lane * ES;
     const int n32 = (int)n_samples;
-#define MF_LD(dst_, rs_, vo_, imm_) asm volatile("buffer_load_dword %0, %1, %2, 0 offen offset:%3" : "=v"(dst_) : "v"(vo_), "s"(rs_), "i"(imm_) : "memory");
-#define MF_LOAD_FRAME(S_, H_)                                                                                  \
+#define MF_LD(dst_, rs_, vo_, imm_)                                                                                              \
+    if constexpr (I16) asm volatile("buffer_load_sshort %0, %1, %2, 0 offen offset:%3" : "=v"(dst_) : "v"(vo_), "s"(rs_), "i"((imm_) / 2) : "memory"); \
+    else asm volatile("buffer_load_dword %0, %1, %2, 0 offen offset:%3" : "=v"(dst_) : "v"(vo_), "s"(rs_), "i"(imm_) : "memory");
+#define MF_LOAD_FRAME(S_, C_, P_)                                                                              \
     {                                                                                                          \
-        const int vc_ = l4 + 4 * S_.back, vp_ = vc_ - 4;   /* vp_ = -4 in lane 0 at a signal's start: out of range, 0 */ \
+        const int vc_ = lES + ES * S_.back, vp_ = vc_ - ES;                                                    \
         asm volatile("s_nop 4" ::: "memory");   /* descriptor words may come out of v_readfirstlane: 5 wait states before a load reads them (hipcc pads nothing in front of asm) */ \
-        MF_LD(cur[0].H_, S_.cur, vc_, 0) MF_LD(cur[1].H_, S_.cur, vc_, 256) MF_LD(cur[2].H_, S_.cur, vc_, 512) MF_LD(cur[3].H_, S_.cur, vc_, 768) \
-        MF_LD(cur[4].H_, S_.cur, vc_, 1024) MF_LD(cur[5].H_, S_.cur, vc_, 1280) MF_LD(cur[6].H_, S_.cur, vc_, 1536) MF_LD(cur[7].H_, S_.cur, vc_, 1792) \
-        MF_LD(prev[0].H_, S_.prev, vp_, 0) MF_LD(prev[1].H_, S_.prev, vp_, 256) MF_LD(prev[2].H_, S_.prev, vp_, 512) MF_LD(prev[3].H_, S_.prev, vp_, 768) \
-        MF_LD(prev[4].H_, S_.prev, vp_, 1024) MF_LD(prev[5].H_, S_.prev, vp_, 1280) MF_LD(prev[6].H_, S_.prev, vp_, 1536) MF_LD(prev[7].H_, S_.prev, vp_, 1792) \
+        MF_LD(C_[0], S_.cur, vc_, 0) MF_LD(C_[1], S_.cur, vc_, 256) MF_LD(C_[2], S_.cur, vc_, 512) MF_LD(C_[3], S_.cur, vc_, 768) \
+        MF_LD(C_[4], S_.cur, vc_, 1024) MF_LD(C_[5], S_.cur, vc_, 1280) MF_LD(C_[6], S_.cur, vc_, 1536) MF_LD(C_[7], S_.cur, vc_, 1792) \
+        MF_LD(P_[0], S_.prev, vp_, 0) MF_LD(P_[1], S_.prev, vp_, 256) MF_LD(P_[2], S_.prev, vp_, 512) MF_LD(P_[3], S_.prev, vp_, 768) \
+        MF_LD(P_[4], S_.prev, vp_, 1024) MF_LD(P_[5], S_.prev, vp_, 1280) MF_LD(P_[6], S_.prev, vp_, 1536) MF_LD(P_[7], S_.prev, vp_, 1792) \
     }
+    // The wait for the 32 loads carries their destination registers as operands: hipcc sees neither the asm loads nor a plain asm
+    // wait, so only a DATA dependence keeps every use of the values behind it (two statements: 30 operands at
+    // most).  tests/test_kernel_resources.py checks on the assembly that nothing touches a destination before the wait.
+#define MF_W8(A_) "+v"(A_[0]), "+v"(A_[1]), "+v"(A_[2]), "+v"(A_[3]), "+v"(A_[4]), "+v"(A_[5]), "+v"(A_[6]), "+v"(A_[7])
 #define MF_REQUEST(fa_)                                                                                        \
     {                                                                                                          \
-        const FrameSrc sa = frame_src(sig, n32, total_frames, (fa_), fpos, d, used);                     \
+        const FrameSrc sa = frame_src<ES>(sig, n32, total_frames, (fa_), fpos, d, used);                 \
         fpos = frame_step_bf(fpos, n_frames);                                                                  \
-        const FrameSrc sb = frame_src(sig, n32, total_frames, (fa_) + 1, fpos, d, used);                 \
+        const FrameSrc sb = frame_src<ES>(sig, n32, total_frames, (fa_) + 1, fpos, d, used);             \
         fpos = frame_step_bf(fpos, n_frames);                                                                  \
-        MF_LOAD_FRAME(sa, x)                                                                                   \
-        MF_LOAD_FRAME(sb, y)                                                                                   \
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                       \
+        MF_LOAD_FRAME(sa, cur_a, prev_a)                                                                       \
+        MF_LOAD_FRAME(sb, cur_b, prev_b)                                                                       \
+        asm volatile("s_waitcnt vmcnt(0)" : MF_W8(cur_a), MF_W8(prev_a) :: "memory");                        \
+        asm volatile("" : MF_W8(cur_b), MF_W8(prev_b) :: "memory");                                          \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
+        if constexpr (I16) {   /* sign-extended 16-bit integers -> (float)s * in_scale, as the host would have converted them */ \
+            _Pragma("unroll") for (int a_ = 0; a_ < 8; ++a_) {                                                 \
+                cur_a[a_] = (float)__builtin_bit_cast(int, cur_a[a_]) * d.in_scale;                            \
+                cur_b[a_] = (float)__builtin_bit_cast(int, cur_b[a_]) * d.in_scale;                            \
+                prev_a[a_] = (float)__builtin_bit_cast(int, prev_a[a_]) * d.in_scale;                          \
+                prev_b[a_] = (float)__builtin_bit_cast(int, prev_b[a_]) * d.in_scale;                          \
+            }                                                                                                  \
+        }                                                                                                      \
     }
     int par = 0;
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, par ^= 1) {
@@ -468,7 +510,7 @@ __global__ __launch_bounds__(256, 4) void mfcc512_kernel(const float* __restrict
             MF_REQUEST(fa)
             c32 x[8];
 #pragma unroll
-            for (int a = 0; a < 8; ++a) x[a] = cur[a] - prev[a] * d.preemph;
+            for (int a = 0; a < 8; ++a) x[a] = c32{cur_a[a], cur_b[a]} - c32{prev_a[a], prev_b[a]} * d.preemph;
             // An all-zero frame (digital silence, or a frame that starts past the end of the signal) must come out as
             // exact zeros -- the package substitutes eps for 0 before the log, -36.04 -- but packed with a live frame it
             // picks up that frame's rounding noise through the split (1e-14 of its power: log ~ -30).  Its power
@@ -501,9 +543,11 @@ __global__ __launch_bounds__(256, 4) void mfcc512_kernel(const float* __restrict
             // below (k and 512 - k, lanes dealt to k so that the two 16-lane halves of a 32-lane service group read runs 128
             // bins apart) then cost 8 LDS cycles of bank conflicts per pair of frames in all, by the guide's bank rules
             // (round 3: slot k + (k >> 3) and k = lane + 64 it: 48 -- SQ_LDS_BANK_CONFLICT was 16.5 % of the LDS cycles)
+            if constexpr (!MF_KNOCK_T3) {
 #pragma unroll
-            for (int k2 = 0; k2 < 8; ++k2) ex[k2 * 72 + lo * 8 + 2 * (lo >> 1) + hi] = x[k2];
-            wave_lds_sync();
+                for (int k2 = 0; k2 < 8; ++k2) ex[k2 * 72 + lo * 8 + 2 * (lo >> 1) + hi] = x[k2];
+                wave_lds_sync();
+            }
             // (frames past the end of the batch have empty descriptors: the loads return zeros)
             // split the two spectra: A = (Z[k] + conj Z[N-k]) / 2, B = (Z[k] - conj Z[N-k]) / (2i); power, energies
             float ea = 0.f, eb = 0.f;
@@ -511,7 +555,9 @@ __global__ __launch_bounds__(256, 4) void mfcc512_kernel(const float* __restrict
             for (int it = 0; it < 5; ++it) {
                 const int k = it < 4 ? (lane & 15) + 16 * it + 64 * (lane >> 5) + 128 * ((lane >> 4) & 1) : 256;
                 const int m = (512 - k) & 511;
-                const c32 p = ex[k + 2 * (k >> 4)], z = ex[m + 2 * (m >> 4)];
+                c32 p, z;
+                if constexpr (MF_KNOCK_T3) { p = x[it]; z = x[7 - it]; }
+                else { p = ex[k + 2 * (k >> 4)]; z = ex[m + 2 * (m >> 4)]; }
                 const c32 sa2 = cadd_conj(p, z), sb2 = csub_conj(p, z);   // 2A, 2iB
                 const c32 qa = sa2 * sa2, qb = sb2 * sb2;
                 const float pa = (qa.x + qa.y) * scale_a, pb = (qb.x + qb.y) * scale_b;
@@ -533,6 +579,7 @@ __global__ __launch_bounds__(256, 4) void mfcc512_kernel(const float* __restrict
             }
         }
         __syncthreads();                                            // P and en complete
+        if constexpr (MF_KNOCK_TAIL) continue;
         // ---- mel filterbank: this wave's share of the (filter tile, bin group) products
         // Independent accumulators, the k-steps outermost: an MFMA's accumulator is then two or three MFMAs old when the next
         // one needs it (v_mfma_f32_16x16x4_f32: 32 cycles to issue, 40 until a dependent one may start).  Round 4 chained all
@@ -556,6 +603,7 @@ __global__ __launch_bounds__(256, 4) void mfcc512_kernel(const float* __restrict
                 else if (it < n_items) acc1 += pacc[s];                                                            \
             }                                                                                                      \
         }
+        static_assert(kMaxItems == 5, "the two rounds below cover products 0-2 and 3-4");
         MF_FB_ROUND(0, 3)
         MF_FB_ROUND(3, 2)
 #undef MF_FB_ROUND
@@ -576,8 +624,14 @@ __global__ __launch_bounds__(256, 4) void mfcc512_kernel(const float* __restrict
         // ---- DCT-II x lifter: waves 0 and 1, one tile of 16 cepstra each; the others go on to the next tile
         if (wave < 2) {
             f32x4v db[2];
-            db[0] = reinterpret_cast<const f32x4v*>(d.f_dct)[(wave * 2 + 0) * 64 + lane];
-            db[1] = reinterpret_cast<const f32x4v*>(d.f_dct)[(wave * 2 + 1) * 64 + lane];
+            if constexpr (MF_KNOCK_DCTLD) {
+                db[0] = f32x4v{1.f, 0.5f, 0.25f, 2.f};
+                db[1] = db[0];
+                asm volatile("" : "+v"(db[0]), "+v"(db[1]));
+            } else {
+                db[0] = reinterpret_cast<const f32x4v*>(d.f_dct)[(wave * 2 + 0) * 64 + lane];
+                db[1] = reinterpret_cast<const f32x4v*>(d.f_dct)[(wave * 2 + 1) * 64 + lane];
+            }
             f32x4v acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
@@ -601,6 +655,7 @@ __global__ __launch_bounds__(256, 4) void mfcc512_kernel(const float* __restrict
 }
 
 #undef MF_REQUEST
+#undef MF_W8
 #undef MF_LOAD_FRAME
 #undef MF_LD
 
@@ -806,39 +861,56 @@ int32_t xvec_mfcc_frames(const xvec_mfcc_plan* p, int64_t n_samples) {
     return 1 + (int32_t)((n_samples - p->dev.frame_len + p->dev.frame_step - 1) / p->dev.frame_step);
 }
 
-int xvec_mfcc(xvec_mfcc_plan* p, const float* signal, int32_t B, int64_t n_samples, float* out, xvec_stream stream) {
+static int mfcc_run(xvec_mfcc_plan* p, const void* signal, bool i16, float in_scale, int32_t B, int64_t n_samples, float* out,
+                    xvec_stream stream) {
     if (!p || !signal || !out) return mfail(XVEC_ERR_ARG, "null argument");
     if (B < 1 || B > 65535 || n_samples < 1) return mfail(XVEC_ERR_ARG, "need 1 <= B <= 65535 and n_samples >= 1");
     const int n_frames = xvec_mfcc_frames(p, n_samples);
     const int64_t total_frames = (int64_t)B * n_frames;
+    MfccDev dv = p->dev;
+    dv.in_scale = in_scale;
+    hipStream_t hs = static_cast<hipStream_t>(stream);
     if (p->fast && total_frames < (int64_t(1) << 31) - fft512::kTile && n_samples < (int64_t(1) << 30)) {
         const int n_tiles = (int)((total_frames + fft512::kTile - 1) / fft512::kTile);
         const int grid = std::min(n_tiles, 4 * p->num_cu);
-        MfccDev dv = p->dev;
         dv.fr_shift = 0;
         while ((1u << dv.fr_shift) < (unsigned)n_frames) ++dv.fr_shift;
         dv.fr_magic = (unsigned)((((unsigned long long)1 << (31 + dv.fr_shift)) + n_frames - 1) / (unsigned)n_frames);
-        fft512::mfcc512_kernel<<<grid, 256, 0, static_cast<hipStream_t>(stream)>>>(signal, n_samples, n_frames, total_frames,
-                                                                              n_tiles, dv, out);
+        if (i16) fft512::mfcc512_kernel<true><<<grid, 256, 0, hs>>>(signal, n_samples, n_frames, total_frames, n_tiles, dv, out);
+        else fft512::mfcc512_kernel<false><<<grid, 256, 0, hs>>>(signal, n_samples, n_frames, total_frames, n_tiles, dv, out);
         if (hipGetLastError() != hipSuccess) return mfail(XVEC_ERR_HIP, "mfcc kernel launch failed");
         return XVEC_OK;
     }
     const int per_wave = wave_floats(p->dev.nfft, p->dev.nbins);
     const size_t lds = ((size_t)per_wave * kWavesPerBlock + p->dev.table_floats) * 4;
-    if (lds > 64 * 1024) {   // nfft 4096: opt in to the larger dynamic LDS once
-        static xvec::LdsOptIn opt;
-        if (opt.ensure(reinterpret_cast<const void*>(mfcc_kernel<0>), 160 * 1024) != hipSuccess)
-            return mfail(XVEC_ERR_HIP, "hipFuncSetAttribute failed");
+    if (lds > 64 * 1024) {   // nfft 4096: opt in to the larger dynamic LDS once per kernel
+        static xvec::LdsOptIn opt_f, opt_s;
+        const hipError_t e = i16 ? opt_s.ensure(reinterpret_cast<const void*>(mfcc_kernel<0, int16_t>), 160 * 1024)
+                                 : opt_f.ensure(reinterpret_cast<const void*>(mfcc_kernel<0, float>), 160 * 1024);
+        if (e != hipSuccess) return mfail(XVEC_ERR_HIP, "hipFuncSetAttribute failed");
     }
     const int grid_x = (n_frames + 2 * kWavesPerBlock - 1) / (2 * kWavesPerBlock);
-    if (p->dev.log2n == 9)
-        mfcc_kernel<9><<<dim3(grid_x, B), kThreads, lds, static_cast<hipStream_t>(stream)>>>(signal, n_samples, n_frames,
-                                                                                           p->dev, out);
-    else
-        mfcc_kernel<0><<<dim3(grid_x, B), kThreads, lds, static_cast<hipStream_t>(stream)>>>(signal, n_samples, n_frames,
-                                                                                           p->dev, out);
+    const dim3 grid(grid_x, B);
+    const float* sf = static_cast<const float*>(signal);
+    const int16_t* ss = static_cast<const int16_t*>(signal);
+    if (p->dev.log2n == 9) {
+        if (i16) mfcc_kernel<9, int16_t><<<grid, kThreads, lds, hs>>>(ss, n_samples, n_frames, dv, out);
+        else mfcc_kernel<9, float><<<grid, kThreads, lds, hs>>>(sf, n_samples, n_frames, dv, out);
+    } else {
+        if (i16) mfcc_kernel<0, int16_t><<<grid, kThreads, lds, hs>>>(ss, n_samples, n_frames, dv, out);
+        else mfcc_kernel<0, float><<<grid, kThreads, lds, hs>>>(sf, n_samples, n_frames, dv, out);
+    }
     if (hipGetLastError() != hipSuccess) return mfail(XVEC_ERR_HIP, "mfcc kernel launch failed");
     return XVEC_OK;
+}
+
+int xvec_mfcc(xvec_mfcc_plan* p, const float* signal, int32_t B, int64_t n_samples, float* out, xvec_stream stream) {
+    return mfcc_run(p, signal, false, 1.0f, B, n_samples, out, stream);
+}
+
+int xvec_mfcc_i16(xvec_mfcc_plan* p, const int16_t* signal, float scale, int32_t B, int64_t n_samples, float* out,
+                  xvec_stream stream) {
+    return mfcc_run(p, signal, true, scale, B, n_samples, out, stream);
 }
 
 }  // extern "C"

@@ -133,7 +133,13 @@ __device__ unsigned long long g_pp16_clk[8];               // block 0: s_memtime
 #define PP_KNOCK_MXROWS ((XVEC_KNOCK & 1024) != 0) // bit 10: ... without the groups (restore / fold / park only)
 #define PP_KNOCK_MXFOLD ((XVEC_KNOCK & 4096) != 0) // bit 12: ... without the fold + park at the end of a tile
 #define PP_KNOCK_ATAP ((XVEC_KNOCK & 8192) != 0)   // bit 13: activation pieces requested for tap 0 only (what sharing one slab between a layer's taps would save)
+#define PP_KNOCK_W2 ((XVEC_KNOCK & 16384) != 0)    // bit 14: every weight piece requested TWICE, counted waits adjusted (cost side of two frame halves with their own weight K-tiles)
+#define PP_KNOCK_EPI4 ((XVEC_KNOCK & 32768) != 0)  // bit 15: no store epilogue in the single-tap store variant only (layer 4; layers 2-3 keep theirs, so it runs on real data)
+#define PP_KNOCK_A5 ((XVEC_KNOCK & 65536) != 0)    // bit 16: no activation pieces in the pooling variant (layer 5 fed from LDS by a fused layer 4)
 #else
+#define PP_KNOCK_W2 false
+#define PP_KNOCK_EPI4 false
+#define PP_KNOCK_A5 false
 #define PP_KNOCK_ATAP false
 #define PP_KNOCK_MXFOLD false
 #define PP_KNOCK_MXMF false
@@ -410,11 +416,13 @@ constexpr int kBlk16 = 16 * kRowB;                // 16 rows of a 32-row block: 
         SB();                                                                       \
         PP_READ_W(b_)                                                               \
         SB();                                                                       \
-        if (req && !PP_KNOCK_DMA && !(PP_KNOCK_ATAP && k2.tap != 0)) PP_ISSUE_A01(b_, k2.so) \
+        if (req && !PP_KNOCK_DMA && !(PP_KNOCK_A5 && POOL) && !(PP_KNOCK_ATAP && k2.tap != 0)) PP_ISSUE_A01(b_, k2.so) \
         SB();                                                                       \
         PP_WAIT_LGKM();                                                             \
         PP_STAMP(0)                                                                 \
-        if (!last) { if (MR == 4) { PP_WAIT_VM(10); } else if (MR == 3) { PP_WAIT_VM(9); } else { PP_WAIT_VM(8); } } \
+        if (PP_KNOCK_A5 && POOL) { }   /* only weight pieces in the queue: nothing of this K-tile is outstanding here */ \
+        else if (PP_KNOCK_W2 && !last) { if (MR == 4) { PP_WAIT_VM(14); } else if (MR == 3) { PP_WAIT_VM(13); } else { PP_WAIT_VM(12); } } \
+        else if (!last) { if (MR == 4) { PP_WAIT_VM(10); } else if (MR == 3) { PP_WAIT_VM(9); } else { PP_WAIT_VM(8); } } \
         else if (!(odd_)) { PP_WAIT_VM_RT(req ? MR + 6 : MR + 4) }                  \
         else { PP_WAIT_VM_RT(req ? mr_req + 6 : 0) }                                \
         PP_STAMP(1)                                                                 \
@@ -441,11 +449,14 @@ constexpr int kBlk16 = 16 * kRowB;                // 16 rows of a 32-row block: 
         PP_STAMP(4)                                                                 \
         if (req && !PP_KNOCK_DMA) {                                                 \
             PP_ISSUE_W(b_, wq)                                                      \
-            if (!(PP_KNOCK_ATAP && k2.tap != 0)) PP_ISSUE_A23(mr_req, b_, k2.so)    \
+            if (PP_KNOCK_W2) PP_ISSUE_W(b_, wq)                                     \
+            if (!(PP_KNOCK_A5 && POOL) && !(PP_KNOCK_ATAP && k2.tap != 0)) PP_ISSUE_A23(mr_req, b_, k2.so) \
         }                                                                           \
         SB();                                                                       \
         PP_STAMP(6)                                                                 \
-        if (!last) { if (MR == 4) { PP_WAIT_VM(10); } else if (MR == 3) { PP_WAIT_VM(8); } else { PP_WAIT_VM(6); } } \
+        if (PP_KNOCK_A5 && POOL) { if (req) { PP_WAIT_VM(4); } else { PP_WAIT_VM(0); } }   /* W of K-tile q+1 behind the four pieces just requested */ \
+        else if (PP_KNOCK_W2 && !last) { if (MR == 4) { PP_WAIT_VM(14); } else if (MR == 3) { PP_WAIT_VM(12); } else { PP_WAIT_VM(10); } } \
+        else if (!last) { if (MR == 4) { PP_WAIT_VM(10); } else if (MR == 3) { PP_WAIT_VM(8); } else { PP_WAIT_VM(6); } } \
         else if (!(odd_)) { PP_WAIT_VM_RT(req ? MR + mr_req + 2 : MR - 2) }         \
         else { PP_WAIT_VM_RT(req ? 2 * mr_req + 2 : 0) }                            \
         PP_STAMP(7)                                                                 \
@@ -1027,6 +1038,9 @@ __device__ __forceinline__ void process_tile(const TdnnArgs& a, char* smem, Stre
     const int64_t row0 = t.m0 + ln.grp * 32 * MR;
 #define PP_ACCV(i_) "v"(acc##i_##00), "v"(acc##i_##01), "v"(acc##i_##02), "v"(acc##i_##03), "v"(acc##i_##10), "v"(acc##i_##11), "v"(acc##i_##12), "v"(acc##i_##13)
     if constexpr (PP_KNOCK_EPI) {
+        asm volatile("" ::PP_ACCV(0), PP_ACCV(1));
+        asm volatile("" ::PP_ACCV(2), PP_ACCV(3));
+    } else if (PP_KNOCK_EPI4 && !POOL && a.n_taps == 1) {
         asm volatile("" ::PP_ACCV(0), PP_ACCV(1));
         asm volatile("" ::PP_ACCV(2), PP_ACCV(3));
     } else if constexpr (!POOL) {

@@ -648,6 +648,12 @@ int xvec_load_tdnn(xvec_handle* h, int layer, const float* weight, const float* 
         return fail(XVEC_ERR_ARG, "BatchNorm tensors must be %s for batch_norm=%d",
                     h->cfg.batch_norm ? "all given" : "all NULL", h->cfg.batch_norm);
     const TdnnGeom& g = h->geo[layer];
+    // A RE-load of this layer while a neighbour's load is still in flight on another stream: that load's re-folds read
+    // Wraw / vec of this layer (refold(layer) reads the producer's BatchNorm, refold(layer + 1) this layer's), which the writes
+    // below replace -- they wait for the neighbours' loads first (a first load has nothing to wait for).
+    if (layer > 0 && h->tdnn_loaded[layer - 1]) HIP_TRY(hipStreamWaitEvent(static_cast<hipStream_t>(stream), h->load_evt[layer - 1], 0));
+    if (layer + 1 < XVEC_NUM_TDNN && h->tdnn_loaded[layer + 1])
+        HIP_TRY(hipStreamWaitEvent(static_cast<hipStream_t>(stream), h->load_evt[layer + 1], 0));
     HIP_TRY(launch_pack_tdnn(weight, bias, bn_weight, bn_bias, bn_mean, bn_var, eps, g, h->Wp[layer],
                              h->vec[layer], h->vec[layer] + g.n_pad, h->vec[layer] + 2 * g.n_pad,
                              static_cast<hipStream_t>(stream)));

@@ -41,6 +41,32 @@ def balanced_order(lengths: Sequence[int], world: int) -> List[List[int]]:
     return [sorted(b) for b in buckets]
 
 
+class Marks:
+    """Time marks of one rank for attributing a multi-GPU line (bench.py `config.per_rank_compute_s`, `config.all_gather_ms`):
+    events on the device's current stream (no host synchronisation between the marks, so measuring does not change what is
+    measured) or, on the CPU (gloo rehearsals), the host clock.  spans() -> seconds between consecutive marks, to be called
+    after the stream has been synchronised."""
+
+    def __init__(self, device=None):
+        self.cuda = device is not None and torch.device(device).type == "cuda"
+        self.device = device
+        self.marks = []
+
+    def mark(self):
+        if self.cuda:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(torch.cuda.current_stream(self.device))
+            self.marks.append(ev)
+        else:
+            import time
+            self.marks.append(time.perf_counter())
+
+    def spans(self):
+        if self.cuda:
+            return [a.elapsed_time(b) * 1e-3 for a, b in zip(self.marks, self.marks[1:])]
+        return [b - a for a, b in zip(self.marks, self.marks[1:])]
+
+
 def gather_embeddings(local: torch.Tensor, n_total: int, group=None,
                       order: Sequence[Sequence[int]] = None, force: bool = False) -> torch.Tensor:
     """All-gather the per-rank [n_local, D] embeddings into [n_total, D] on every rank.
@@ -87,7 +113,7 @@ def gather_embeddings(local: torch.Tensor, n_total: int, group=None,
 
 def extract_sharded(extract_fn: Callable[[torch.Tensor], torch.Tensor], make_batch: Callable[[int, int], torch.Tensor],
                     n_total: int, batch_size: int = 256, group=None, force_collective: bool = False,
-                    embed_dim: int = None, device=None) -> torch.Tensor:
+                    embed_dim: int = None, device=None, marks: "Marks" = None) -> torch.Tensor:
     """Utterance-sharded extraction job (BASELINE configs[3]).
 
     make_batch(lo, hi) returns the device tensor [hi-lo, T, C] for global utterances
@@ -98,7 +124,10 @@ def extract_sharded(extract_fn: Callable[[torch.Tensor], torch.Tensor], make_bat
     all-gather with a [0, D] shard, D = `embed_dim` or, when that is not given, learnt from its peers by one
     scalar all-reduce (every rank takes part in it, and only when the last rank's block is empty).  Such a rank has no
     tensor to take its device from: pass `device`, or -- with the "nccl" backend -- have torch.cuda.set_device(local_rank)
-    called before (bench.py does), since the fallback is the process's CURRENT device."""
+    called before (bench.py does), since the fallback is the process's CURRENT device.
+
+    `marks` (a Marks): three marks -- start, this rank's own extraction done, exchange done -- so that a scaling line can say
+    which part of a rank's time was its own work and which the collective (including the wait for slower ranks)."""
     import torch.distributed as dist
     if n_total < 1:                        # on EVERY rank, before any collective: nobody is left waiting in one
         raise ValueError("extract_sharded: nothing to extract (n_total < 1)")
@@ -106,10 +135,14 @@ def extract_sharded(extract_fn: Callable[[torch.Tensor], torch.Tensor], make_bat
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     lo, hi = shard_bounds(n_total, rank, world)
     parts = []
+    if marks is not None:
+        marks.mark()
     for b0 in range(lo, hi, batch_size):
         b1 = min(b0 + batch_size, hi)
         parts.append(extract_fn(make_batch(b0, b1)))
     local = torch.cat(parts, 0) if parts else None
+    if marks is not None:
+        marks.mark()
     last_lo, last_hi = shard_bounds(n_total, world - 1, world)
     if world > 1 and last_hi <= last_lo:                       # some rank has no utterances: same answer on every rank
         if device is None:
@@ -122,7 +155,10 @@ def extract_sharded(extract_fn: Callable[[torch.Tensor], torch.Tensor], make_bat
             D = int(t.item())
         if local is None:
             local = torch.zeros((0, D), dtype=torch.float32, device=device)
-    return gather_embeddings(local, n_total, group, force=force_collective)
+    full = gather_embeddings(local, n_total, group, force=force_collective)
+    if marks is not None:
+        marks.mark()
+    return full
 
 
 def extract_balanced(extract_ragged: Callable[[List[int]], torch.Tensor], lengths: Sequence[int], group=None,

@@ -45,19 +45,26 @@ class MfccFrontEnd:
     def num_frames(self, n_samples: int) -> int:
         return int(_hip.lib.xvec_mfcc_frames(self._plan, n_samples))
 
-    def __call__(self, waves: torch.Tensor) -> torch.Tensor:
+    def __call__(self, waves: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
+        """waves: float [B, n_samples], or torch.int16 PCM (what scipy.io.wavfile.read yields, reference dataset.py:125),
+        converted inside the kernel as (float)s * scale -- bit for bit the result for `waves.float() * scale`, at half the
+        bytes over PCIe.  `scale` applies to int16 input only (1.0 = the raw PCM range the reference's call sees)."""
         if not waves.is_cuda:
             raise RuntimeError(f"MfccFrontEnd: expected a tensor on a HIP device, got {waves.device}")
         if waves.dim() == 1:
             waves = waves[None]
         if waves.dim() != 2 or waves.shape[1] < 1:
             raise ValueError(f"MfccFrontEnd: expected waves[B, n_samples], got {tuple(waves.shape)}")
-        w = waves.detach().float().contiguous()
+        i16 = waves.dtype == torch.int16
+        w = waves.detach().contiguous() if i16 else waves.detach().float().contiguous()
         B, n = w.shape
         out = torch.empty((B, self.num_frames(n), self.numcep), dtype=torch.float32, device=w.device)
         with torch.cuda.device(w.device):
-            rc = _hip.lib.xvec_mfcc(self._plan, w.data_ptr(), B, n, out.data_ptr(),
-                                    torch.cuda.current_stream(w.device).cuda_stream)
+            stream = torch.cuda.current_stream(w.device).cuda_stream
+            if i16:
+                rc = _hip.lib.xvec_mfcc_i16(self._plan, w.data_ptr(), float(scale), B, n, out.data_ptr(), stream)
+            else:
+                rc = _hip.lib.xvec_mfcc(self._plan, w.data_ptr(), B, n, out.data_ptr(), stream)
         if rc != _hip.OK:
             raise _hip.XvecError(rc, _hip.lib.xvec_mfcc_last_error().decode())
         return out

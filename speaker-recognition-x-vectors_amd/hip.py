@@ -93,6 +93,7 @@ _SIGS = {
     "xvec_mfcc_last_error": (C.c_char_p, []),
     "xvec_mfcc_frames": (C.c_int32, [_vp, _i64]),
     "xvec_mfcc": (C.c_int, [_vp, _f32p, _i32, _i64, _f32p, _vp]),
+    "xvec_mfcc_i16": (C.c_int, [_vp, _vp, C.c_float, _i32, _i64, _f32p, _vp]),
     # include/xvec_score.h
     "xvec_score_last_error": (C.c_char_p, []),
     "xvec_gemm_nt_f64": (C.c_int, [_vp, _i64, _vp, _i64, _i64, _i64, _i32, _vp, _vp, C.c_double, C.c_double, _vp,
@@ -100,6 +101,8 @@ _SIGS = {
     "xvec_score_workspace_bytes": (C.c_size_t, [_i64, _i64, _i32]),
     "xvec_plda_score": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _vp, _vp, _vp, C.c_double, C.c_double, _vp, _vp,
                                   C.c_size_t, _vp]),
+    "xvec_plda_score_lowrank": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _i32, _vp, _vp, _vp, C.c_double, C.c_double, _vp,
+                                          _vp, C.c_size_t, _vp]),
     "xvec_cosine_score": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _vp, _vp, C.c_size_t, _vp]),
 }
 EXPORTS = tuple(_SIGS)

@@ -85,10 +85,25 @@ def plda_constants(F, Sigma, scaling_factor=1.0):
     return tot_inv - tmp, tot_inv @ ac @ tmp, float(cst)
 
 
-class PldaScorer:
-    """PLDA model (mean, F, Sigma) prepared for scoring on one HIP device."""
+def plda_lowrank(F, Sigma, scaling_factor=1.0):
+    """(L, W, Z, plda_cst) with Phi = -L Z L' and Psi = L W L' exactly (Woodbury): tot = F F' + Sigma, L = tot^-1 F [D, R],
+    G = F' L, W = (I - G^2)^-1, Z = W G.  Model-only, host, numpy float64; what xvec_plda_score_lowrank takes instead of the
+    dense Phi, Psi of `plda_constants` (the same scores to rounding over K = R instead of D)."""
+    F = np.asarray(F, dtype=np.float64)
+    Sigma = np.asarray(Sigma, dtype=np.float64)
+    _, _, cst = plda_constants(F, Sigma, scaling_factor)
+    L = np.linalg.solve(F @ F.T + Sigma, F)
+    G = F.T @ L
+    W = np.linalg.inv(np.eye(F.shape[1]) - G @ G)
+    return L, W, W @ G, cst
 
-    def __init__(self, mean, F, Sigma, scaling_factor=1.0, device="cuda:0"):
+
+class PldaScorer:
+    """PLDA model (mean, F, Sigma) prepared for scoring on one HIP device.  `lowrank=None` takes the low-rank form whenever
+    F has fewer columns than rows (the reference trains rank_f = 50 .. 200 on 512-d x-vectors), `False` forces the dense
+    Phi / Psi products of the package's formulation."""
+
+    def __init__(self, mean, F, Sigma, scaling_factor=1.0, device="cuda:0", lowrank=None):
         self.device = _require_device(device)
         F = np.asarray(F, dtype=np.float64)
         self.dim = int(F.shape[0])
@@ -99,10 +114,18 @@ class PldaScorer:
         self.plda_cst = cst
         self._mean = _dev_f64(mean, self.device)
         # Psi^T and Phi^T stacked in ONE [2 dim, dim] buffer: the library then forms [e Psi | e Phi] in one launch
-        # (xvec_plda_score: 2 x 156 tiles of 128 x 128 at 4874 x-vectors fill the 512 block slots better than 156 twice)
+        # (xvec_plda_score: centring, the product and the row dots 0.5 e Phi e' in that launch, the score matrix in a second)
         self._psiphi_t = _dev_f64(np.concatenate([np.asarray(psi).T, np.asarray(phi).T], 0), self.device)
         self._psi_t = self._psiphi_t[: psi.shape[0]]
         self._phi_t = self._psiphi_t[psi.shape[0]:]
+        self.rank = int(F.shape[1])
+        self.lowrank = (self.rank < self.dim) if lowrank is None else bool(lowrank)
+        if self.lowrank:
+            if self.rank > self.dim:
+                raise ValueError("PldaScorer: the low-rank form needs rank <= dim")
+            L, W, Z, _ = plda_lowrank(F, Sigma, scaling_factor)
+            self._l_t = _dev_f64(L.T, self.device)
+            self._wz_t = _dev_f64(np.concatenate([W.T, -Z.T], 0), self.device)
         self._ws = None
 
     def _workspace(self, ne, nt):
@@ -121,10 +144,16 @@ class PldaScorer:
         ws = self._workspace(ne, 0 if t is None else nt)
         out = torch.empty((ne, nt), dtype=torch.float64, device=self.device)
         with torch.cuda.device(self.device):
-            _check(_hip.lib.xvec_plda_score(e.data_ptr(), ne, t.data_ptr() if t is not None else None, nt, self.dim,
-                                            self._mean.data_ptr(), self._psi_t.data_ptr(), self._phi_t.data_ptr(),
-                                            self.plda_cst, self.scaling_factor, out.data_ptr(), ws.data_ptr(),
-                                            ws.numel(), _stream(self.device)))
+            if self.lowrank:
+                _check(_hip.lib.xvec_plda_score_lowrank(e.data_ptr(), ne, t.data_ptr() if t is not None else None, nt,
+                                                        self.dim, self.rank, self._mean.data_ptr(), self._l_t.data_ptr(),
+                                                        self._wz_t.data_ptr(), self.plda_cst, self.scaling_factor,
+                                                        out.data_ptr(), ws.data_ptr(), ws.numel(), _stream(self.device)))
+            else:
+                _check(_hip.lib.xvec_plda_score(e.data_ptr(), ne, t.data_ptr() if t is not None else None, nt, self.dim,
+                                                self._mean.data_ptr(), self._psi_t.data_ptr(), self._phi_t.data_ptr(),
+                                                self.plda_cst, self.scaling_factor, out.data_ptr(), ws.data_ptr(),
+                                                ws.numel(), _stream(self.device)))
         return out
 
 
@@ -183,7 +212,9 @@ def fast_PLDA_scoring(enroll, test, ndx, mu, F, Sigma, p_known=0.0, scaling_fact
         if tm is not None:
             mask = np.asarray(tm)[np.ix_(m_keep, s_keep)]
         e_names, t_names = m_names, s_names
-    same = enroll is test and e_names.tolist() == t_names.tolist()
+    # the reference scores the test set against ITSELF through two stat objects built from the same arrays
+    # (plda_score_stat.py:19-20): same names and same vectors take the library's self path (upper triangle of tiles only)
+    same = e_names.tolist() == t_names.tolist() and (e_x is t_x or (e_x.shape == t_x.shape and np.array_equal(e_x, t_x)))
     scorer = PldaScorer(mu, F, Sigma, scaling_factor=scaling_factor, device=device)
     mat = scorer.score(e_x, None if same else t_x)
     return Scores(e_names, t_names, mat.cpu().numpy(), mask)

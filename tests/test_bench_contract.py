@@ -45,8 +45,13 @@ def test_bench_line(extra):
             assert isinstance(cfg[key], float) and cfg[key] > 0, key
         assert cfg["bf16_embeddings_per_s"] > cfg["bf16x3_embeddings_per_s"] > d["value"]   # bf16 matrix rate is 16x the fp32 one
         # next rows N3 / N4 in the driver's own line
-        for key in ("wave_utt_per_s", "wave_bf16_utt_per_s", "mfcc_us_per_batch", "plda_score_ms_n4874"):
+        for key in ("wave_utt_per_s", "wave_bf16_utt_per_s", "mfcc_us_per_batch", "plda_score_ms_n4874",
+                    # round 6: configs[2] x [4], configs[3] x [4] at its own size, host waveforms -> bf16
+                    "ragged_bf16_utt_per_s", "ragged_bf16_valid_frames_per_s", "job100k_bf16_embeddings_per_s",
+                    "wave_bf16_pcie_inclusive_utt_per_s", "wave_bf16_pcie_inclusive_f32_samples_utt_per_s", "plda_dense_score_ms_n4874"):
             assert isinstance(cfg[key], float) and cfg[key] > 0, key
+        assert cfg["ragged_bf16_utt_per_s"] > cfg["ragged_utt_per_s"] and cfg["job100k_bf16_embeddings_per_s"] > cfg["job100k_embeddings_per_s"]
+        assert cfg["plda_score_ms_n4874"] < cfg["plda_dense_score_ms_n4874"]          # rank 200 of 512
         assert cfg["wave_bf16_utt_per_s"] > cfg["wave_utt_per_s"] and cfg["mfcc_us_per_batch"] < 500 and cfg["plda_score_ms_n4874"] < 20
     else:
         assert "bf16_embeddings_per_s" not in cfg
@@ -73,6 +78,10 @@ def test_plain_python_launch_of_two_ranks_dry_run(extra, scaling):
     assert len(lines) == 1, lines
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["data"] == "dry-run" and d["scaling"] == scaling and d["value"] > 0
+    # attribution fields of a multi-rank line: one compute time per rank, the collective's span
+    pr = d["config"]["per_rank_compute_s"]
+    assert len(pr["ranks"]) == 2 and pr["min"] == min(pr["ranks"]) and pr["max"] == max(pr["ranks"]) and pr["min"] >= 0
+    assert d["config"]["all_gather_ms"]["max"] >= d["config"]["all_gather_ms"]["min"] >= 0
 
 
 def test_self_launch_propagates_failure():
@@ -93,6 +102,9 @@ def test_self_launch_on_the_gpu_with_the_collective():
            "'--cpu-budget','0','--preroll','0.1']))"]
     d = _one_line(cmd)
     assert d["n_gpus"] == 1 and d["data"] == "synthetic" and "all-gather" in d["config"]["sharding"] and d["value"] > 0
+    # attribution of a --gpus N line: every rank's own time and the collective's, one entry per rank
+    assert d["config"]["per_rank_compute_s"]["max"] >= d["config"]["per_rank_compute_s"]["min"] > 0
+    assert len(d["config"]["per_rank_compute_s"]["ranks"]) == 1 and d["config"]["all_gather_ms"]["max"] > 0
 
 
 @pytest.mark.gpu

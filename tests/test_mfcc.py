@@ -154,3 +154,80 @@ def test_mfcc_silence_and_errors():
         fe(torch.zeros(1, 1600))
     with pytest.raises(Exception):
         xa.MfccFrontEnd(nfft=500)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision,tol", [("bf16", 1e-2), ("fp32", 1e-4)])
+def test_waveforms_to_x_vectors_at_the_bench_size(sd42, precision, tol):
+    """The whole product pipeline of `bench.py --workload wave` against the two oracles chained, at ITS size: 256 x 48 000
+    samples -> MfccFrontEnd (T = 299: 285 pooled frames, an odd row count for the large-batch kernels) -> extract_x_vec,
+    eight sampled utterances against mfcc_oracle.mfcc -> float32 (the reference's samples.float(), main.py:137) ->
+    xvector_oracle.extract_x_vec in float64.  VERDICT r05 item 4."""
+    import xvector_amd as xa
+    import xvector_oracle as xo
+    from conftest import assert_parity, float_params
+    base = [_speechlike(48000, 200 + i) for i in range(16)]
+    waves = np.stack([base[i % 16] * (0.06 + 0.94 * (i // 16) / 15.0) for i in range(256)]).astype(np.float32)
+    fe = xa.MfccFrontEnd()
+    m = xa.XVectorModel(precision=precision)
+    m.load_state_dict(sd42)
+    m = m.to("cuda:0").eval()
+    feats = fe(torch.from_numpy(waves).to("cuda:0"))
+    assert feats.shape == (256, 299, 24)
+    got = m.extract_x_vec(feats)
+    if precision == "bf16":
+        assert m.last_dispatch() == ["first", "pp", "pp", "pp", "pp"]
+    idx = [0, 1, 17, 100, 128, 200, 254, 255]
+    ref_feats = np.stack([mo.mfcc(waves[i], 16000, numcep=24, nfilt=26, nfft=512) for i in idx])
+    assert_parity(feats[idx], ref_feats, 1e-4, "mfcc at the bench size", elem_tol=1e-3)
+    p64 = xo.cast_params(float_params(sd42), torch.float64)
+    ref = xo.extract_x_vec(torch.from_numpy(ref_feats).float().double(), p64)
+    assert_parity(got[idx], ref, tol, f"waveforms -> x-vectors, {precision}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw,n_samples,B,scale", [(dict(), 48000, 5, 1.0), (dict(), 16001, 3, 1.0 / 32768), (dict(), 401, 2, 0.37),
+                                                   (dict(nfft=1024), 9000, 2, 1.0), (dict(nfft=512, nfilt=40, numcep=20), 9000, 2, 3.0e-5)])
+def test_mfcc_int16_input_equals_float_input_bit_for_bit(kw, n_samples, B, scale):
+    """16-bit PCM as scipy.io.wavfile.read yields it (reference dataset.py:125), converted inside the kernel as (float)s * scale:
+    one fp32 rounding, exactly what the float path is given for `pcm.float() * scale` -- so the two results are EQUAL, on both
+    kernels (nfft = 512 and the general one), for any scale; and both match the oracle on the converted signal."""
+    import xvector_amd as xa
+    from conftest import assert_parity
+    fe = xa.MfccFrontEnd(**kw)
+    pcm = np.stack([np.round(_speechlike(n_samples, 300 + i) * (3000.0 + 9000.0 * i)) for i in range(B)]).astype(np.int16)
+    pcm[0, :3] = [-32768, 32767, -1]                           # the range's ends
+    t = torch.from_numpy(pcm).to("cuda:0")
+    got_i = fe(t, scale=scale)
+    as_float = t.float() * torch.tensor(scale, dtype=torch.float32)
+    got_f = fe(as_float)
+    assert got_i.dtype == torch.float32 and torch.equal(got_i, got_f)
+    okw = {"numcep": 24, "nfilt": 26, "nfft": 512, **kw}
+    ref = np.stack([mo.mfcc(w, 16000, **okw) for w in as_float.cpu().numpy()])
+    assert_parity(got_i.cpu().numpy(), ref, 1e-4, f"mfcc of int16 PCM {kw}", elem_tol=1e-3)
+
+
+@pytest.mark.gpu
+def test_first_frame_previous_samples():
+    """Pre-emphasis at a signal's start, sample by sample: y[0] = x[0] (no previous sample), y[64 a] = x[64 a] - 0.97 x[64 a - 1].
+    The nfft = 512 kernel addresses x[n - 1] of frame 0 as lane offset -4 (-2 for 16-bit PCM) plus the immediate 256 a, which is
+    in range for a >= 1 and must read as zero for a = 0 (csrc/mfcc.hip, MF_LOAD_FRAME).  Spikes at exactly the samples 64 a - 1
+    and 64 a make a wrong neighbour visible in frame 0's coefficients."""
+    import xvector_amd as xa
+    from conftest import assert_parity
+    fe = xa.MfccFrontEnd()
+    for variant in range(3):
+        x = 0.01 * np.random.default_rng(variant).standard_normal((2, 4000)).astype(np.float32)
+        for a in range(1, 7):
+            x[0, 64 * a - 1] += 1.0 + 0.1 * a                  # the previous sample of lane 0's a-th value
+            if variant == 1:
+                x[0, 64 * a] -= 0.7
+        if variant == 2:
+            x[:, 0] = 2.5                                      # a large first sample: nothing may be subtracted from it
+        got = fe(torch.from_numpy(x).to("cuda:0")).cpu().numpy()
+        ref = np.stack([mo.mfcc(w, 16000, numcep=24, nfilt=26, nfft=512) for w in x])
+        assert_parity(got[:, :3], ref[:, :3], 1e-4, f"first frames, variant {variant}", elem_tol=1e-3)
+        pcm = torch.from_numpy(np.round(x * 8000).astype(np.int16)).to("cuda:0")
+        got16 = fe(pcm, scale=1.0 / 8000).cpu().numpy()
+        ref16 = np.stack([mo.mfcc(w, 16000, numcep=24, nfilt=26, nfft=512) for w in (pcm.float() / 8000).cpu().numpy()])
+        assert_parity(got16[:, :3], ref16[:, :3], 1e-4, f"first frames, 16-bit PCM, variant {variant}", elem_tol=1e-3)

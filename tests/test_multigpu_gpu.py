@@ -126,6 +126,9 @@ def test_bench_multi_rank_code_path_world1(tmp_path):
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 1 and out["value"] > 0 and "all-gather" in out["config"]["sharding"]
+    # attribution: the rank's own time and the collective's, by events on the launch stream
+    assert 0 < out["config"]["per_rank_compute_s"]["min"] <= out["config"]["per_rank_compute_s"]["max"] < out["steps"] * out["ms_per_step"] * 1e-3 * 1.05
+    assert out["config"]["all_gather_ms"]["max"] > 0
 
 
 # ------------------------------------------------------------------------------- N2 on the GPU

@@ -102,23 +102,42 @@ def test_gemm_nt_f64_vs_numpy(M, N, K):
     assert _rel(got0, a @ b.T) < F64_TOL
 
 
+def test_lowrank_factors_reproduce_phi_and_psi():
+    """Phi = -L Z L', Psi = L W L' (the identity the low-rank scorer rests on), on the host in float64."""
+    from xvector_amd import scoring
+    for dim, rank in [(512, 200), (512, 50), (64, 20), (25, 25), (40, 1)]:
+        mean, F, Sigma = po.make_plda(dim, rank, seed=3 + rank)
+        phi, psi, cst = po.plda_constants(F, Sigma)
+        L, W, Z, cst_lr = scoring.plda_lowrank(F, Sigma)
+        assert L.shape == (dim, rank) and W.shape == Z.shape == (rank, rank) and cst_lr == pytest.approx(cst, rel=1e-14)
+        assert np.abs(phi + L @ Z @ L.T).max() <= 1e-12 * np.abs(phi).max()
+        assert np.abs(psi - L @ W @ L.T).max() <= 1e-12 * np.abs(psi).max()
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("dim,rank,ne,nt", [(512, 150, 300, 517), (512, 200, 129, 129), (200, 50, 64, 33), (25, 25, 7, 300)])
-def test_plda_score_vs_oracle(dim, rank, ne, nt):
+@pytest.mark.parametrize("lowrank", [True, False])
+@pytest.mark.parametrize("dim,rank,ne,nt", [(512, 150, 300, 517), (512, 200, 129, 129), (200, 50, 64, 33), (25, 25, 7, 300),
+                                            (512, 1, 70, 40), (96, 37, 130, 131)])
+def test_plda_score_vs_oracle(dim, rank, ne, nt, lowrank):
     from xvector_amd import scoring
     mean, F, Sigma = po.make_plda(dim, rank, seed=dim + rank)
     e, t = _xvecs(ne, dim, 1, mean), _xvecs(nt, dim, 2, mean)
-    scorer = scoring.PldaScorer(mean, F, Sigma)
+    scorer = scoring.PldaScorer(mean, F, Sigma, lowrank=lowrank)
+    assert scorer.lowrank == lowrank
     got = scorer.score(e, t).cpu().numpy()
     ref = po.fast_plda_scoring(e, t, mean, F, Sigma)
     assert got.shape == (ne, nt) and got.dtype == np.float64
     assert _rel(got, ref) < 1e-9
-    # enrol against itself (the reference's use) takes the shared-statistics path
+    # enrol against itself (the reference's use, plda_score_stat.py:19-20) walks the upper triangle of tiles only and
+    # writes every element twice: symmetric bit for bit
     got_self = scorer.score(e).cpu().numpy()
     assert _rel(got_self, po.fast_plda_scoring(e, e, mean, F, Sigma)) < 1e-9
-    np.testing.assert_allclose(got_self, got_self.T, rtol=1e-9, atol=1e-9 * np.abs(got_self).max())
+    assert np.array_equal(got_self, got_self.T)
+    # ... and the two-set path given the same vectors twice (full tile walk, no mirroring) agrees with it to rounding
+    got_two = scorer.score(e, e).cpu().numpy()
+    assert _rel(got_two, got_self) < 1e-12
     # scaling factor
-    got_s = scoring.PldaScorer(mean, F, Sigma, scaling_factor=0.5).score(e, t).cpu().numpy()
+    got_s = scoring.PldaScorer(mean, F, Sigma, scaling_factor=0.5, lowrank=lowrank).score(e, t).cpu().numpy()
     assert _rel(got_s, po.fast_plda_scoring(e, t, mean, F, Sigma, scaling_factor=0.5)) < 1e-9
 
 
@@ -147,6 +166,8 @@ def test_plda_scores_dropin_surface():
     assert list(sc.modelset) == ids and list(sc.segset) == ids
     assert sc.scoremat.shape == (n, n) and sc.scoremat.dtype == np.float64 and sc.scoremask.all()
     assert _rel(sc.scoremat, po.fast_plda_scoring(x, x, plda.mean, plda.F, plda.Sigma)) < 1e-9
+    # en_stat and te_stat are two objects built from the same vectors (plda_score_stat.py:19-20): the self path
+    assert np.array_equal(sc.scoremat, sc.scoremat.T)
     # the lookup the reference does per trial (plda_score_stat.py:66-74)
     i = int(np.where(sc.modelset == ids[5])[0][0])
     j = int(np.where(sc.segset == ids[17])[0][0])
@@ -163,20 +184,23 @@ def test_cosine_vs_oracle():
     assert _rel(got, po.cosine_scoring(e, t)) < F64_TOL
     self_scores = scoring.cosine_scores(e).cpu().numpy()
     np.testing.assert_allclose(np.diag(self_scores), 1.0, atol=1e-13)
+    assert np.array_equal(self_scores, self_scores.T)
+    assert _rel(self_scores, po.cosine_scoring(e, e)) < F64_TOL
 
 
 @pytest.mark.gpu
-def test_full_size_properties():
+@pytest.mark.parametrize("lowrank", [True, False])
+def test_full_size_properties(lowrank):
     """VoxCeleb1 test-set size (4874 utterances, 512-d): symmetry, diagonal = self-score formula, and
     a sampled block against the oracle."""
     from xvector_amd import scoring
     dim, n = 512, 4874
     mean, F, Sigma = po.make_plda(dim, 200, seed=21)
     x = _xvecs(n, dim, 5, mean)
-    scorer = scoring.PldaScorer(mean, F, Sigma)
+    scorer = scoring.PldaScorer(mean, F, Sigma, lowrank=lowrank)
     s = scorer.score(x)
     assert s.shape == (n, n)
-    assert float((s - s.T).abs().max()) < 1e-9 * float(s.abs().max())
+    assert torch.equal(s, s.T)              # 780 of the 1521 tiles are computed, the rest are their mirror images
     phi, psi, cst = po.plda_constants(F, Sigma)
     xc = x - mean
     diag_ref = np.einsum("ij,ij->i", xc @ (phi + psi), xc) + cst
@@ -184,3 +208,8 @@ def test_full_size_properties():
     rows, cols = slice(4800, 4874), slice(1000, 1100)
     ref = po.fast_plda_scoring(x[rows], x[cols], mean, F, Sigma)
     assert _rel(s[rows, cols].cpu().numpy(), ref) < 1e-9
+    ref_d = po.fast_plda_scoring(x[4790:4874], x[4790:4874], mean, F, Sigma)        # a diagonal tile and its ragged edge
+    assert _rel(s[4790:, 4790:].cpu().numpy(), ref_d) < 1e-9
+    # the non-self path (full tile walk) is unchanged by the self path's shortcut
+    two = scorer.score(x[:700], x[300:1500])
+    assert _rel(two.cpu().numpy(), s[:700, 300:1500].cpu().numpy()) < 1e-12

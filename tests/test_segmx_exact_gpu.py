@@ -149,7 +149,9 @@ def _check(m, sd, x, lengths):
     assert n_seg >= bpc and sensed
 
 
-@pytest.mark.parametrize("B,T", [(20, 300), (52, 300), (63, 300), (100, 300), (128, 300), (37, 517)])
+# (160 x 300 and 256 x 300 -- BASELINE configs[4]'s own batch -- are the shapes whose blocks cut their ranges into four-unit tiles:
+#  the host side holds two [rows, 1500] fp64 matrices, 1.8 GB at 256 x 300)
+@pytest.mark.parametrize("B,T", [(20, 300), (52, 300), (63, 300), (100, 300), (128, 300), (37, 517), (160, 300), (256, 300)])
 def test_segmx_sums_fixed(sd42, synth, B, T):
     m, sd = _model(sd42)
     _check(m, sd, torch.from_numpy(synth.make_mfcc(B, T, seed=B)).to(DEV), None)

@@ -56,11 +56,9 @@ __device__ __forceinline__ void dma16(const i32x4& rsrc, unsigned dst, int voff,
 #define MF(i_, j_, af_, wf_) \
     asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i_][j_]) : "v"(af_), "v"(wf_));
 
-template <int MODE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void onewave_kernel(
-    const char* __restrict__ A, const char* __restrict__ W, float* __restrict__ out, int n_stage4, long a_block_bytes,
-    int a_blocked, int a_share) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+template <int MODE, int JS>
+__device__ __forceinline__ void onewave_body(char* smem, const char* __restrict__ A, const char* __restrict__ W, float* __restrict__ out,
+                                             int n_stage4, long a_block_bytes, int a_blocked, int a_share) {
     constexpr bool RD = (MODE & 1) != 0, DMA = (MODE & 2) != 0;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -126,6 +124,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         af[3] = af[1];
     }
 
+    // JS: the MFMA of a row behind which this wave issues its piece (stagger = 1: wave w at 2 w + 1 instead of all four
+    // waves at 6 -- after every barrier the waves run in lockstep: four 1-KiB requests reach the CU's address path together)
+    constexpr int jslot = JS;
     int st = 0;                                    // stage being computed; requests go out for st + 3
     // STAGE(slot): rows i = 0..7; behind the MFMAs of row i: A fragment of row i + 2 (rows 8, 9 = the next stage's 0, 1),
     // next-stage W fragment i, DMA piece i of stage st + 3 into slot (slot + 3) & 3
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     RDF(wf[wnxt_][i], w_rd + (((slot_) + 1) & 3) * kSlot + i * 1024)                     \
                     SB();                                                                                \
                 }                                                                                        \
-                if (j == 6 && DMA) {                                                                     \
+                if (DMA && j == jslot) {                                                                 \
                     SB();                                                                                \
                     ISSUE_PIECE(st + 3, ((slot_) + 3) & 3, i)                                            \
                     SB();                                                                                \
@@ -178,6 +179,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     if (out == reinterpret_cast<float*>(1)) out[0] = af[0].x + wf[0][0].x + wf[1][0].x;
 }
 
+template <int MODE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void onewave_kernel(
+    const char* __restrict__ A, const char* __restrict__ W, float* __restrict__ out, int n_stage4, long a_block_bytes,
+    int a_blocked, int a_share, int stagger) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int sel = stagger ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 4;
+    if (sel == 0) onewave_body<MODE, 1>(smem, A, W, out, n_stage4, a_block_bytes, a_blocked, a_share);
+    else if (sel == 1) onewave_body<MODE, 3>(smem, A, W, out, n_stage4, a_block_bytes, a_blocked, a_share);
+    else if (sel == 2) onewave_body<MODE, 5>(smem, A, W, out, n_stage4, a_block_bytes, a_blocked, a_share);
+    else if (sel == 3) onewave_body<MODE, 7>(smem, A, W, out, n_stage4, a_block_bytes, a_blocked, a_share);
+    else onewave_body<MODE, 6>(smem, A, W, out, n_stage4, a_block_bytes, a_blocked, a_share);
+}
+
 static unsigned short f2bf(float f) {
     unsigned u;
     memcpy(&u, &f, 4);
@@ -186,7 +200,7 @@ static unsigned short f2bf(float f) {
 
 template <int MODE>
 static double run(const char* A, const char* W, float* out, int n_stage4, long a_block_bytes, int reps, float* ms_out,
-                  int a_blocked = 0, int a_share = 0) {
+                  int a_blocked = 0, int a_share = 0, int stagger = 0) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(onewave_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
@@ -194,7 +208,7 @@ static double run(const char* A, const char* W, float* out, int n_stage4, long a
     std::vector<float> t;
     for (int rep = 0; rep < reps; ++rep) {
         hipEventRecord(e0);
-        onewave_kernel<MODE><<<256, 256, kLds>>>(A, W, out, n_stage4, a_block_bytes, a_blocked, a_share);
+        onewave_kernel<MODE><<<256, 256, kLds>>>(A, W, out, n_stage4, a_block_bytes, a_blocked, a_share, stagger);
         hipEventRecord(e1);
         hipEventSynchronize(e1);
         float ms;
@@ -234,14 +248,16 @@ int main(int argc, char** argv) {
     // warm the clock state: ~2 s of the full loop
     for (int i = 0; i < 200; ++i) run<3>(A, W, out, n_stage4, a_block_bytes, 50, &ms);
     // the DMA stream's variants: activation source row-major / blocked, one slab per three taps
-    for (int blocked = 0; blocked < 2; ++blocked)
-        for (int share = 0; share < 2; ++share) {
-            float m2, m3;
-            run<2>(A, W, out, n_stage4, a_block_bytes, 200, &m2, blocked, share);
-            const double p3 = run<3>(A, W, out, n_stage4, a_block_bytes, 200, &m3, blocked, share);
-            printf("A %s, %s: DMA only %.4f ms | reads+DMA %.4f ms %.3f PF\n", blocked ? "blocked (1-KiB contiguous pieces)" : "row-major (64 B of each row)",
-                   share ? "one slab per 3 taps" : "every stage", m2, m3, p3);
-        }
+    for (int stagger = 0; stagger < 2; ++stagger)
+        for (int blocked = 0; blocked < 2; ++blocked)
+            for (int share = 0; share < 2; ++share) {
+                float m2, m3;
+                run<2>(A, W, out, n_stage4, a_block_bytes, 200, &m2, blocked, share, stagger);
+                const double p3 = run<3>(A, W, out, n_stage4, a_block_bytes, 200, &m3, blocked, share, stagger);
+                printf("%s | A %s, %s: DMA only %.4f ms | reads+DMA %.4f ms %.3f PF\n", stagger ? "waves' DMA slots staggered" : "all waves' DMA at MFMA 6 ",
+                       blocked ? "blocked (1-KiB contiguous pieces)" : "row-major (64 B of each row)   ",
+                       share ? "one slab per 3 taps" : "every stage        ", m2, m3, p3);
+            }
     printf("onewave_bound: %s operands, %d x 4 stages of 32 per launch (layer 2 of B = 256: 109.5 stages per CU)\n", zero ? "ZERO" : "relu-normal / uniform", n_stage4);
     for (int rd = 0; rd < rounds; ++rd) {
         const double p0 = run<0>(A, W, out, n_stage4, a_block_bytes, 200, &ms);

@@ -77,13 +77,18 @@ constexpr int kWavesPerBlock = kThreads / 64;
 // L2N: log2(nfft) fixed at compile time (9: the reference's nfft = 512), or 0 = taken from `d`.  With
 // constant trip counts the sample loads of a frame, the two butterfly groups of a pass and the
 // bins of the split are issued together instead of one LDS / memory round trip at a time.
-// S: sample type, float or int16_t (16-bit PCM as scipy.io.wavfile.read yields it, reference dataset.py:125: every sample is
-// (float)s * d.in_scale, exactly what the float path is given when the caller converts on the host).
-template <int L2N, typename S>
-__global__ __launch_bounds__(kThreads) void mfcc_kernel(const S* __restrict__ sig, int64_t n_samples,
+// Samples: fp32, or (i16 != 0) 16-bit PCM as scipy.io.wavfile.read yields it (reference dataset.py:125), every sample entering as
+// (float)s * d.in_scale -- exactly what the float path is given when the caller converts on the host.  A RUN-TIME flag on
+// purpose: one instantiation per L2N, so everything behind the sample fetch is the same instructions for both input types
+// and the two results are equal bit for bit by construction (as two template instances hipcc contracted the multiply-adds
+// of the two differently: 1 ulp apart).
+template <int L2N>
+__global__ __launch_bounds__(kThreads) void mfcc_kernel(const void* __restrict__ sig_v, int i16, int64_t n_samples,
                                                         int n_frames, MfccDev d, float* __restrict__ out) {
-    constexpr bool I16 = sizeof(S) == 2;
-    auto smp = [&](const S* p_, int64_t i_) -> float { return I16 ? (float)p_[i_] * d.in_scale : (float)p_[i_]; };
+    // (__fmul_rn: a product of its own, rounded once -- as a plain `*` hipcc may fuse it into the pre-emphasis' multiply-add)
+    auto smp = [&](int64_t i_) -> float {
+        return i16 ? __fmul_rn((float)static_cast<const int16_t*>(sig_v)[i_], d.in_scale) : static_cast<const float*>(sig_v)[i_];
+    };
     const int log2n = L2N ? L2N : d.log2n;
     const int nfft = L2N ? (1 << L2N) : d.nfft;
     extern __shared__ float lds[];
@@ -105,7 +110,7 @@ __global__ __launch_bounds__(kThreads) void mfcc_kernel(const S* __restrict__ si
     const int fa = 2 * (blockIdx.x * kWavesPerBlock + wave), b = blockIdx.y;
     if (fa >= n_frames) return;                               // whole wave leaves together (no later block barrier)
     const bool has_b = fa + 1 < n_frames;
-    const S* s = sig + (int64_t)b * n_samples;
+    const int64_t s0 = (int64_t)b * n_samples;             // the utterance's first sample
     const int64_t start = (int64_t)fa * d.frame_step;
     const int used = d.frame_len < nfft ? d.frame_len : nfft;   // rfft(frame, nfft) truncates long frames
 
@@ -115,8 +120,8 @@ __global__ __launch_bounds__(kThreads) void mfcc_kernel(const S* __restrict__ si
         float va = 0.f, vb = 0.f;
         if (n < used) {
             const int64_t ga = start + n, gb = ga + d.frame_step;
-            if (ga < n_samples) va = (ga == 0) ? smp(s, 0) : smp(s, ga) - d.preemph * smp(s, ga - 1);
-            if (has_b && gb < n_samples) vb = smp(s, gb) - d.preemph * smp(s, gb - 1);
+            if (ga < n_samples) va = (ga == 0) ? smp(s0) : smp(s0 + ga) - d.preemph * smp(s0 + ga - 1);
+            if (has_b && gb < n_samples) vb = smp(s0 + gb) - d.preemph * smp(s0 + gb - 1);
         }
         z[zpos((int)bitrev((unsigned)n, log2n))] = make_float2(va, vb);
     }
@@ -491,10 +496,10 @@ __global__ __launch_bounds__(256, 4) void mfcc512_kernel(const void* __restrict_
         __builtin_amdgcn_sched_barrier(0);                                                                     \
         if constexpr (I16) {   /* sign-extended 16-bit integers -> (float)s * in_scale, as the host would have converted them */ \
             _Pragma("unroll") for (int a_ = 0; a_ < 8; ++a_) {                                                 \
-                cur_a[a_] = (float)__builtin_bit_cast(int, cur_a[a_]) * d.in_scale;                            \
-                cur_b[a_] = (float)__builtin_bit_cast(int, cur_b[a_]) * d.in_scale;                            \
-                prev_a[a_] = (float)__builtin_bit_cast(int, prev_a[a_]) * d.in_scale;                          \
-                prev_b[a_] = (float)__builtin_bit_cast(int, prev_b[a_]) * d.in_scale;                          \
+                cur_a[a_] = __fmul_rn((float)__builtin_bit_cast(int, cur_a[a_]), d.in_scale);                            \
+                cur_b[a_] = __fmul_rn((float)__builtin_bit_cast(int, cur_b[a_]), d.in_scale);                            \
+                prev_a[a_] = __fmul_rn((float)__builtin_bit_cast(int, prev_a[a_]), d.in_scale);                          \
+                prev_b[a_] = __fmul_rn((float)__builtin_bit_cast(int, prev_b[a_]), d.in_scale);                          \
             }                                                                                                  \
         }                                                                                                      \
     }
@@ -883,23 +888,15 @@ static int mfcc_run(xvec_mfcc_plan* p, const void* signal, bool i16, float in_sc
     }
     const int per_wave = wave_floats(p->dev.nfft, p->dev.nbins);
     const size_t lds = ((size_t)per_wave * kWavesPerBlock + p->dev.table_floats) * 4;
-    if (lds > 64 * 1024) {   // nfft 4096: opt in to the larger dynamic LDS once per kernel
-        static xvec::LdsOptIn opt_f, opt_s;
-        const hipError_t e = i16 ? opt_s.ensure(reinterpret_cast<const void*>(mfcc_kernel<0, int16_t>), 160 * 1024)
-                                 : opt_f.ensure(reinterpret_cast<const void*>(mfcc_kernel<0, float>), 160 * 1024);
-        if (e != hipSuccess) return mfail(XVEC_ERR_HIP, "hipFuncSetAttribute failed");
+    if (lds > 64 * 1024) {   // nfft 4096: opt in to the larger dynamic LDS once
+        static xvec::LdsOptIn opt;
+        if (opt.ensure(reinterpret_cast<const void*>(mfcc_kernel<0>), 160 * 1024) != hipSuccess)
+            return mfail(XVEC_ERR_HIP, "hipFuncSetAttribute failed");
     }
     const int grid_x = (n_frames + 2 * kWavesPerBlock - 1) / (2 * kWavesPerBlock);
     const dim3 grid(grid_x, B);
-    const float* sf = static_cast<const float*>(signal);
-    const int16_t* ss = static_cast<const int16_t*>(signal);
-    if (p->dev.log2n == 9) {
-        if (i16) mfcc_kernel<9, int16_t><<<grid, kThreads, lds, hs>>>(ss, n_samples, n_frames, dv, out);
-        else mfcc_kernel<9, float><<<grid, kThreads, lds, hs>>>(sf, n_samples, n_frames, dv, out);
-    } else {
-        if (i16) mfcc_kernel<0, int16_t><<<grid, kThreads, lds, hs>>>(ss, n_samples, n_frames, dv, out);
-        else mfcc_kernel<0, float><<<grid, kThreads, lds, hs>>>(sf, n_samples, n_frames, dv, out);
-    }
+    if (p->dev.log2n == 9) mfcc_kernel<9><<<grid, kThreads, lds, hs>>>(signal, i16 ? 1 : 0, n_samples, n_frames, dv, out);
+    else mfcc_kernel<0><<<grid, kThreads, lds, hs>>>(signal, i16 ? 1 : 0, n_samples, n_frames, dv, out);
     if (hipGetLastError() != hipSuccess) return mfail(XVEC_ERR_HIP, "mfcc kernel launch failed");
     return XVEC_OK;
 }

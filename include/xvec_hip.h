@@ -193,8 +193,7 @@ enum {
     XVEC_KERNEL_NONE = 0,
     XVEC_KERNEL_TILE128 = 1, /* xvec::tdnn_kernel<...>          128x128 tiles (csrc/tdnn_layer.hip) */
     XVEC_KERNEL_PP = 2,      /* xvec::pp16::tdnn_pp_kernel<POOL, X3>  256-channel LDS-DMA mapping, bf16 / bf16x3 at large batches (csrc/tdnn_pp16.hip) */
-    XVEC_KERNEL_FIRST = 3,   /* xvec::first::tdnn_first_kernel / first3::tdnn_first3_kernel  layer 1 of the bf16 / bf16x3 path, streaming (csrc/tdnn_first.hip) */
-    XVEC_KERNEL_PW = 4       /* xvec::pw::tdnn_pw_kernel  one wave per SIMD, 256 AGPR accumulators: the store layers of plain bf16 at large batches (csrc/tdnn_pw.hip) */
+    XVEC_KERNEL_FIRST = 3    /* xvec::first::tdnn_first_kernel / first3::tdnn_first3_kernel  layer 1 of the bf16 / bf16x3 path, streaming (csrc/tdnn_first.hip) */
 };
 int xvec_get_dispatch(const xvec_handle* h, int* kernels, int* n);
 

@@ -127,29 +127,6 @@ __global__ void pack_tdnn_weight_ktile_kernel(const float* __restrict__ W, const
         Wt[i] = (__bf16)v;
     }
 }
-// bf16 weights for tdnn_pw.hip, STAGE major: [256-channel column block][stage of 32 k][256 rows][32 k], stage = 32-channel slab
-// c of the input x tap t, taps innermost (stage index c n_taps + t).  Row 16 j + c of a wave's 128 rows (wave column r >> 7)
-// holds channel 128 (r >> 7) + 8 c + j: lane c's eight 16x16 accumulators of a frame then own EIGHT adjacent channels, which
-// the kernel's epilogue writes as one 16-byte piece.
-__global__ void pack_tdnn_weight_stage_kernel(const float* __restrict__ W, const float* __restrict__ in_scale, TdnnGeom g,
-                                              __bf16* __restrict__ Wt) {
-    const int64_t total = (int64_t)g.n_pad * g.k_pad;
-    const int nst = g.k_pad / 32;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
-         i += (int64_t)gridDim.x * blockDim.x) {
-        const int w = (int)(i & 31), r = (int)((i >> 5) & 255);
-        const int64_t t = i >> 13;                       // (column block, stage)
-        const int cb = (int)(t / nst), st = (int)(t % nst);
-        const int n = cb * 256 + (r & ~127) + 8 * (r & 15) + ((r >> 4) & 7);
-        const int tap = st % g.n_taps, c = (st / g.n_taps) * 32 + w;
-        float v = 0.f;
-        if (n < g.cout && tap < g.src_taps && c < g.src_cin) {
-            v = W[(int64_t)n * (g.src_taps * g.src_cin) + tap * g.src_cin + c];
-            if (in_scale) v *= in_scale[c];        // (see pack_tdnn_weight_frag_kernel)
-        }
-        Wt[i] = (__bf16)v;
-    }
-}
 // The same for the bf16x3 form of tdnn_pp16.hip: every K-tile three times -- W_hi, W_lo = bf16(W - W_hi), W_hi again --
 // in the order its K loop meets them (hi slab x W_hi, hi slab x W_lo, lo slab x W_hi): [column block][3 * K-tile + j][256][64]
 __global__ void pack_tdnn_weight_ktile3_kernel(const float* __restrict__ W, TdnnGeom g, __bf16* __restrict__ Wt) {
@@ -174,12 +151,6 @@ __global__ void pack_tdnn_weight_ktile3_kernel(const float* __restrict__ W, Tdnn
 hipError_t launch_pack_tdnn_rows_bf16x3(const float* W, const TdnnGeom& geo, void* Wr48, hipStream_t s) {
     if (geo.n_pad % 256 != 0) return hipSuccess;
     pack_tdnn_weight_ktile3_kernel<<<1024, 256, 0, s>>>(W, geo, static_cast<__bf16*>(Wr48));
-    return hipGetLastError();
-}
-hipError_t launch_pack_tdnn_stage_bf16(const float* W, const float* in_scale, const TdnnGeom& geo, void* Ws16, hipStream_t s) {
-    // (only layers whose taps are not folded: source tap = kernel tap, source channel = slab channel)
-    if (geo.n_pad % 256 != 0 || geo.k_pad % 32 != 0 || geo.n_taps != geo.src_taps || geo.kpt_pad != geo.src_cin) return hipSuccess;
-    pack_tdnn_weight_stage_kernel<<<1024, 256, 0, s>>>(W, in_scale, geo, static_cast<__bf16*>(Ws16));
     return hipGetLastError();
 }
 hipError_t launch_pack_tdnn_rows_bf16(const float* W, const float* in_scale, const TdnnGeom& geo, void* Wr16, hipStream_t s) {

@@ -69,9 +69,6 @@ struct xvec_handle {
     void* Wp16[XVEC_NUM_TDNN];         // bf16, fragment-major
     void* Wp16b;                       // layer 1 only: the same with the bias in the two spare k slots (tdnn_first.hip)
     void* Wr16[XVEC_NUM_TDNN];         // bf16, K-tile major [n_pad/256][k_pad/64][256][64] (tdnn_pp16.hip: both operands reach LDS by DMA)
-    void* Ws16[XVEC_NUM_TDNN];         // bf16, stage major [n_pad/256][k_pad/32][256][32] (tdnn_pw.hip)
-    bool use_pw;                       // one-wave-per-SIMD kernel for the store layers of plain bf16 (XVEC_PW=0/1: A/B runs)
-    int64_t min_frames;                // shortest utterance of the call in flight (input frames): tdnn_pw.hip needs >= 32 output rows each
     bool use_pp;                       // large-batch bf16 mapping enabled (XVEC_PP=0 disables it: A/B runs)
     int pp_min_tenths;                 // ... from this many tenths of a 64-frame unit per CU on (18; XVEC_PP_MIN_TENTHS: crossover sweeps)
     int pp_cu_pct;                     // XVEC_PP_CU_PCT (diagnostic): percentage of the CUs the large-batch kernel's grid covers (0 = all)
@@ -293,15 +290,6 @@ int run_tdnn(xvec_handle* h, int layer, TdnnVariant v, const void* X, int ldx, i
             a.pair_period = 0;
             d.pool_units = units;
             d.pool_bpc = bpc;
-            // the store layers of plain bf16: one wave per SIMD (tdnn_pw.hip) where its shapes hold and every utterance keeps
-            // at least 32 output rows (a tile's activation slab has room for eight utterance boundaries)
-            if (h->use_pw && !x3 && v == TdnnVariant::kBf16 && h->Ws16[layer] && h->min_frames - out_map.cum >= 32 &&
-                g.n_taps == g.src_taps && g.kpt_pad == g.src_cin && tdnn_pw_applicable(a)) {
-                a.W = h->Ws16[layer];
-                HIP_TRY(launch_tdnn_pw(a, s));
-                h->last_kernel[layer] = d.kernel = XVEC_KERNEL_PW;
-                return XVEC_OK;
-            }
             HIP_TRY(launch_tdnn_pp16(a, v == TdnnVariant::kBf16Pool, s));
             h->last_kernel[layer] = d.kernel = XVEC_KERNEL_PP;
             return XVEC_OK;
@@ -345,7 +333,6 @@ int refold(xvec_handle* h, int layer, hipStream_t s) {
     const float* sh = layer > 0 ? h->vec[layer - 1] + 2 * h->geo[layer - 1].n_pad : nullptr;
     HIP_TRY(launch_pack_tdnn_bf16(h->Wraw[layer], sc, g, h->Wp16[layer], s));
     HIP_TRY(launch_pack_tdnn_rows_bf16(h->Wraw[layer], sc, g, h->Wr16[layer], s));
-    HIP_TRY(launch_pack_tdnn_stage_bf16(h->Wraw[layer], sc, g, h->Ws16[layer], s));
     HIP_TRY(launch_fold_bias(h->Wraw[layer], h->braw[layer], sh, g, h->vec16[layer], s));
     if (layer == 0 && g.kpt + 2 <= g.k_pad) {      // the streaming kernel's copy: bias in the spare k slots
         HIP_TRY(launch_pack_tdnn_bf16(h->Wraw[layer], nullptr, g, h->Wp16b, s));
@@ -564,9 +551,6 @@ int xvec_create(const xvec_cfg* cfg, xvec_handle** out) {
         if (h->blocks_per_cu < 1) h->blocks_per_cu = 1;
         const char* p = getenv("XVEC_PP");
         h->use_pp = !(p && atoi(p) == 0);
-        const char* pw = getenv("XVEC_PW");
-        h->use_pw = pw && atoi(pw) != 0;
-        h->min_frames = 0;
         const char* mt = getenv("XVEC_PP_MIN_TENTHS");
         h->pp_min_tenths = mt && atoi(mt) > 0 ? atoi(mt) : 18;
         const char* cp = getenv("XVEC_PP_CU_PCT");
@@ -579,7 +563,6 @@ int xvec_create(const xvec_cfg* cfg, xvec_handle** out) {
         const TdnnGeom& g = h->geo[i];
         if (hipMalloc(&h->Wp16[i], (size_t)h->geo16[i].n_pad * h->geo16[i].k_pad * 2) != hipSuccess ||
             hipMalloc(&h->Wr16[i], (size_t)h->geo16[i].n_pad * h->geo16[i].k_pad * 2) != hipSuccess ||
-            hipMalloc(&h->Ws16[i], (size_t)h->geo16[i].n_pad * h->geo16[i].k_pad * 2) != hipSuccess ||
             (i == 0 && hipMalloc(&h->Wp16b, (size_t)h->geo16[i].n_pad * h->geo16[i].k_pad * 2) != hipSuccess) ||
             hipMalloc(&h->Wp48[i], (size_t)h->geo16[i].n_pad * h->geo16[i].k_pad * 2 * 2) != hipSuccess ||
             hipMalloc(&h->Wr48[i], (size_t)h->geo16[i].n_pad * h->geo16[i].k_pad * 2 * 3) != hipSuccess ||
@@ -627,7 +610,6 @@ void xvec_destroy(xvec_handle* h) {
         if (h->Wp[i]) (void)hipFree(h->Wp[i]);
         if (h->Wp16[i]) (void)hipFree(h->Wp16[i]);
         if (h->Wr16[i]) (void)hipFree(h->Wr16[i]);
-        if (h->Ws16[i]) (void)hipFree(h->Ws16[i]);
         if (h->Wp48[i]) (void)hipFree(h->Wp48[i]);
         if (h->Wr48[i]) (void)hipFree(h->Wr48[i]);
         if (h->vec[i]) (void)hipFree(h->vec[i]);
@@ -755,20 +737,17 @@ int xvec_forward(xvec_handle* h, const float* x, const int32_t* lengths_host, in
             HIP_TRY(launch_pack_rows(x, nullptr, B, T, C, h->cin_pad, xp, false, s));
             rows = xp;
         }
-        h->min_frames = T;
         return forward_rows(h, rows, h->cin_pad, nullptr, B, T, p, mode, dtype, out, ws, s);
     }
 
     // ragged: pack the valid frames, run the stack on sum(lengths) rows only
-    int64_t total = 0, shortest = T;
+    int64_t total = 0;
     for (int i = 0; i < B; ++i) {
         const int n = lengths_host[i];
         if (n <= XVEC_TOTAL_CONTEXT || n > T)
             return fail(XVEC_ERR_ARG, "lengths[%d]=%d outside [%d, T=%d]", i, n, XVEC_TOTAL_CONTEXT + 1, T);
         total += n;
-        shortest = n < shortest ? n : shortest;
     }
-    h->min_frames = shortest;
     const Plan p = make_plan(h, total, B);
     if (workspace_bytes < p.bytes)
         return fail(XVEC_ERR_WORKSPACE, "workspace too small: %zu < %zu", workspace_bytes, p.bytes);
@@ -790,15 +769,12 @@ int xvec_forward_packed(xvec_handle* h, const float* x_packed, const int64_t* of
     HIP_TRY(guard.enter(h->cfg.device));
     if (!offsets_host) return fail(XVEC_ERR_ARG, "null offsets");
     if (offsets_host[0] != 0) return fail(XVEC_ERR_ARG, "offsets[0] must be 0");
-    int64_t shortest = INT64_MAX;
     for (int i = 0; i < B; ++i) {
         const int64_t n = offsets_host[i + 1] - offsets_host[i];
         if (n <= XVEC_TOTAL_CONTEXT)
             return fail(XVEC_ERR_ARG, "utterance %d has %lld frames; need at least %d", i, (long long)n,
                         XVEC_TOTAL_CONTEXT + 1);
-        shortest = n < shortest ? n : shortest;
     }
-    h->min_frames = shortest;
     hipStream_t s = static_cast<hipStream_t>(stream);
     char* ws = static_cast<char*>(workspace);
     const int64_t total = offsets_host[B];
@@ -831,7 +807,6 @@ int xvec_tdnn_layer(xvec_handle* h, int layer, const float* x, int32_t B, int32_
     HIP_TRY(guard.enter(h->cfg.device));
     const TdnnGeom& g = h->geo[layer];
     if (B < 1 || T <= g.ctx_span) return fail(XVEC_ERR_ARG, "need B>=1 and T>%d (got B=%d T=%d)", g.ctx_span, B, T);
-    h->min_frames = T;
     const Plan p = make_plan(h, (int64_t)B * T, B);
     if (workspace_bytes < p.bytes)
         return fail(XVEC_ERR_WORKSPACE, "workspace too small: %zu < %zu", workspace_bytes, p.bytes);

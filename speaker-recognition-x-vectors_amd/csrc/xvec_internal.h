@@ -129,12 +129,6 @@ hipError_t launch_tdnn(const TdnnArgs& a, TdnnVariant v, hipStream_t s);
 //   groups_total = ceil(rows / 64) units, blocks_per_col ranges per column (>= 1.8 units each: the measured crossover with the 128x128 kernel).
 //   terms == 2 (bf16x3): X / Y are hi and lo planes x_plane_bytes / y_plane_bytes apart, W the tripled packing below.
 hipError_t launch_tdnn_pp16(const TdnnArgs& a, bool pool, hipStream_t s);
-// One wave per SIMD, 256 accumulator registers in AGPRs (tdnn_pw.hip): plain bf16, store epilogue (layers 2-4), the same grid as
-// tdnn_pp16.hip (n_tiles = n_pad / 256 columns, groups_total units of 64 frames, blocks_per_col ranges).  W = stage-major bf16
-// [n_pad/256][k_pad/32][256][32] (launch_pack_tdnn_stage_bf16).  Every utterance must keep >= 32 output rows (caller's check).
-bool tdnn_pw_applicable(const TdnnArgs& a);
-hipError_t launch_tdnn_pw(const TdnnArgs& a, hipStream_t s);
-hipError_t launch_pack_tdnn_stage_bf16(const float* W, const float* in_scale, const TdnnGeom& geo, void* Ws16, hipStream_t s);
 // Layer 1 of the bf16 path as a streaming kernel (tdnn_first.hip): weights resident in registers, 16-byte stores.
 // Reads TdnnArgs as the 128x128 kernel does (Wf = fragment-major bf16 weights); X holds the caller's fp32 rows.
 // (Wf = the layer's fragment-major copy WITH the bias in k slots kpt, kpt + 1: launch_patch_bias_kslots)

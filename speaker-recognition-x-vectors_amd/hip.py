@@ -30,7 +30,7 @@ OK, ERR_ARG, ERR_HIP, ERR_STATE, ERR_WORKSPACE, ERR_TOO_LARGE = 0, 1, 2, 3, 4, 5
 F32, BF16, BF16X3 = 0, 1, 2
 MODE_LOGITS, MODE_POOLED, MODE_XVEC6, MODE_XVEC7 = 0, 5, 6, 7
 SEG6, SEG7, OUTPUT = 6, 7, 8
-KERNEL_NAMES = {0: None, 1: "tile128", 2: "pp", 3: "first", 4: "pw"}      # XVEC_KERNEL_*
+KERNEL_NAMES = {0: None, 1: "tile128", 2: "pp", 3: "first"}      # XVEC_KERNEL_*
 TIMING_NAMES = ("tdnn1", "tdnn2", "tdnn3", "tdnn4", "tdnn5_pool", "pool_finalize",
                 "segment6", "segment7", "output", "pack")
 

@@ -242,13 +242,11 @@ namespace fft512 {
 
 #ifdef XVEC_MFKNOCK
 // Timing-only knock-outs of mfcc512_kernel (-DXVEC_MFKNOCK=mask; results are garbage):
-//   bit 0: no third transpose, the split reads its operands from the lane's own registers (bound of an in-register split)
+//   (bit 0, round 6: the split without its LDS round trip -- the bound of what ships now as the ds_bpermute split)
 //   bit 1: the DCT fragments are not fetched per tile      bit 2: no tile tail at all (filterbank, log, DCT, two barriers)
-#define MF_KNOCK_T3 ((XVEC_MFKNOCK & 1) != 0)
 #define MF_KNOCK_DCTLD ((XVEC_MFKNOCK & 2) != 0)
 #define MF_KNOCK_TAIL ((XVEC_MFKNOCK & 4) != 0)
 #else
-#define MF_KNOCK_T3 false
 #define MF_KNOCK_DCTLD false
 #define MF_KNOCK_TAIL false
 #endif
@@ -424,6 +422,9 @@ __global__ __launch_bounds__(256, 4) void mfcc512_kernel(const void* __restrict_
     float* LE = P + kTile * kPS;                                    // [16][kLS] log mel energies
     float* en = LE + kTile * kLS;                                   // [2][16] frame energies (by tile parity)
     const int hi = lane >> 3, lo = lane & 7, q = lane >> 4, row = lane & 15;
+    // the split's partner lane (holds Z[512 - k] of this lane's bins k = hi + 8 lo + 64 k2, k2 < 4) as a ds_bpermute byte address
+    const int part_addr = 4 * (8 * ((8 - hi) & 7) + (hi ? 7 - lo : (8 - lo) & 7));
+    const int bin0 = hi + 8 * lo;
 
     // twiddles: step 1's depend on the lane and stay in registers, step 2's (W_64^(c k), 56 values) sit in LDS
     c32 w1[7];
@@ -544,37 +545,37 @@ __global__ __launch_bounds__(256, 4) void mfcc512_kernel(const void* __restrict_
 #pragma unroll
             for (int c = 0; c < 8; ++c) x[c] = ex[hi * 72 + lo * 9 + c];   // lane = 8 k0 + k1
             dft8(x);                                                // over c -> k2
-            // Z[k = k0 + 8 k1 + 64 k2] at slot k + 2 (k >> 4) = 72 k2 + 8 k1 + 2 (k1 >> 1) + k0: this store and the split's reads
-            // below (k and 512 - k, lanes dealt to k so that the two 16-lane halves of a 32-lane service group read runs 128
-            // bins apart) then cost 8 LDS cycles of bank conflicts per pair of frames in all, by the guide's bank rules
-            // (round 3: slot k + (k >> 3) and k = lane + 64 it: 48 -- SQ_LDS_BANK_CONFLICT was 16.5 % of the LDS cycles)
-            if constexpr (!MF_KNOCK_T3) {
+            // lane 8 k0 + k1 now holds Z[k0 + 8 k1 + 64 k2] in x[k2].  The split needs Z[k] and Z[512 - k] for k < 256 (k2 < 4):
+            // 512 - k = (8 - k0) + 8 (7 - k1) + 64 (7 - k2) for k0 != 0, 8 (8 - k1) + 64 (7 - k2) for k0 = 0 != k1 -- ONE
+            // partner lane (part_addr) holds all four, in x[7], x[6], x[5], x[4] -- and 64 (8 - k2) in lane 0 itself (its own
+            // x[0], x[7], x[6], x[5]).  Eight ds_bpermute_b32 fetch them (round 6; until then a third transpose through LDS:
+            // eight 8-byte writes, a wait and ten reads per pair, 16.7 % of a wave's time with the power rows).
+            // (the elements go through float temporaries: __builtin_bit_cast(int, v.y) on an ELEMENT of an ext_vector reads
+            //  element 0 with hipcc 7.2 -- the imaginary parts came back as copies of the real parts)
+            c32 f[4];
 #pragma unroll
-                for (int k2 = 0; k2 < 8; ++k2) ex[k2 * 72 + lo * 8 + 2 * (lo >> 1) + hi] = x[k2];
-                wave_lds_sync();
+            for (int m = 0; m < 4; ++m) {
+                const float sx = x[7 - m].x, sy = x[7 - m].y;
+                f[m].x = __int_as_float(__builtin_amdgcn_ds_bpermute(part_addr, __float_as_int(sx)));
+                f[m].y = __int_as_float(__builtin_amdgcn_ds_bpermute(part_addr, __float_as_int(sy)));
             }
-            // (frames past the end of the batch have empty descriptors: the loads return zeros)
-            // split the two spectra: A = (Z[k] + conj Z[N-k]) / 2, B = (Z[k] - conj Z[N-k]) / (2i); power, energies
             float ea = 0.f, eb = 0.f;
 #pragma unroll
-            for (int it = 0; it < 5; ++it) {
-                const int k = it < 4 ? (lane & 15) + 16 * it + 64 * (lane >> 5) + 128 * ((lane >> 4) & 1) : 256;
-                const int m = (512 - k) & 511;
-                c32 p, z;
-                if constexpr (MF_KNOCK_T3) { p = x[it]; z = x[7 - it]; }
-                else { p = ex[k + 2 * (k >> 4)]; z = ex[m + 2 * (m >> 4)]; }
-                const c32 sa2 = cadd_conj(p, z), sb2 = csub_conj(p, z);   // 2A, 2iB
+            for (int k2 = 0; k2 < 4; ++k2) {
+                c32 z;           // Z[512 - k]: lane 0 pairs 64 k2 with 64 (8 - k2)
+                if (k2 == 0) { z.x = lane == 0 ? x[0].x : f[0].x; z.y = lane == 0 ? x[0].y : f[0].y; }
+                else { z.x = lane == 0 ? f[k2 - 1].x : f[k2].x; z.y = lane == 0 ? f[k2 - 1].y : f[k2].y; }
+                const c32 sa2 = cadd_conj(x[k2], z), sb2 = csub_conj(x[k2], z);   // 2A, 2iB
                 const c32 qa = sa2 * sa2, qb = sb2 * sb2;
                 const float pa = (qa.x + qa.y) * scale_a, pb = (qb.x + qb.y) * scale_b;
-                if (it < 4) {
-                    P[r0 * kPS + k] = pa;
-                    P[(r0 + 1) * kPS + k] = pb;
-                    ea += pa;
-                    eb += pb;
-                } else if (lane == 0) {
-                    ea += pa;
-                    eb += pb;
-                }
+                P[r0 * kPS + bin0 + 64 * k2] = pa;
+                P[(r0 + 1) * kPS + bin0 + 64 * k2] = pb;
+                ea += pa;
+                eb += pb;
+            }
+            if (lane == 0) {     // bin 256 = Z[256] = lane 0's x[4], its own partner: A[256] = Re, B[256] = Im (energies only)
+                ea += (4.f * x[4].x * x[4].x) * scale_a;
+                eb += (4.f * x[4].y * x[4].y) * scale_b;
             }
             ea = wave_sum(ea);                                     // (vector-ALU cross-lane adds: __shfl_xor is six LDS round trips per value)
             eb = wave_sum(eb);

@@ -77,6 +77,7 @@ int main(void) {
         bad.numcep = 40;                             /* more cepstra than filters */
         EXPECT(xvec_mfcc_create(&bad, &p) == XVEC_ERR_ARG && p == 0);
         EXPECT(xvec_mfcc(0, buf, 1, 16000, buf, 0) == XVEC_ERR_ARG);
+        EXPECT(xvec_mfcc_i16(0, (const int16_t*)buf, 1.0f, 1, 16000, buf, 0) == XVEC_ERR_ARG);
         EXPECT(xvec_mfcc_frames(0, 16000) <= 0);
         xvec_mfcc_destroy(0);
         EXPECT(strlen(xvec_mfcc_last_error()) > 0);
@@ -86,6 +87,10 @@ int main(void) {
         double d[8] = {0};
         EXPECT(xvec_gemm_nt_f64(0, 4, d, 4, 2, 2, 4, 0, 0, 0.0, 1.0, d, 2, 0) != XVEC_OK);
         EXPECT(xvec_cosine_score(0, 2, d, 2, 4, d, 0, 0, 0) != XVEC_OK);
+        EXPECT(xvec_plda_score(d, 0, 0, 0, 4, d, d, d, 0.0, 1.0, d, d, sizeof d, 0) != XVEC_OK);             /* empty enrol set */
+        EXPECT(xvec_plda_score_lowrank(d, 2, 0, 0, 4, 5, d, d, d, 0.0, 1.0, d, d, sizeof d, 0) != XVEC_OK);    /* rank > dim */
+        EXPECT(xvec_plda_score_lowrank(d, 2, 0, 0, 4, 2, d, 0, d, 0.0, 1.0, d, d, sizeof d, 0) != XVEC_OK);    /* null factor */
+        EXPECT(xvec_plda_score_lowrank(d, 2, 0, 0, 4, 2, d, d, d, 0.0, 1.0, d, d, 8, 0) != XVEC_OK);           /* workspace too small */
         EXPECT(xvec_score_workspace_bytes(-1, 2, 4) == 0);
         EXPECT(strlen(xvec_score_last_error()) > 0);
     }

@@ -232,12 +232,13 @@ __global__ __launch_bounds__(kThreads) void mfcc_kernel(const void* __restrict__
 //    planes of 64 padded to 72); the twiddles never change: step 1's seven per lane live in registers, step 2's 56 in LDS;
 //  * a block of four waves owns 16 consecutive frames of the batch (frames are numbered through the whole batch:
 //    76 544 = 4784 x 16 for 256 x 299, no ragged last tile per utterance), two pairs per wave, and leaves their
-//    power spectra in LDS as a [16][256] matrix;
+//    power spectra in LDS as sixteen rows of 256 (eight in an array, eight in the waves' exchange regions: kExRow);
 //  * mel filterbank and DCT x lifter are matrix products on v_mfma_f32_16x16x4_f32 (exact fp32): P[16 x 256] x
 //    FB^T[256 x 32] with the filterbank's zero blocks skipped (filters 0-15 end at bin 87, filters 16-25 begin
 //    at bin 77: 18 of 32 blocks of 16 bins), split over the four waves and summed in wave order; log;
-//    [16 x 32] x DCTL^T[32 x 32].  The B fragments are packed per lane on the host and stay in registers:
-//    blocks are persistent (four per CU) and walk the tiles with a grid stride.
+//    [16 x 32] x DCTL^T[32 x 32].  The B fragments are packed per lane on the host and fetched per tile (L2-resident):
+//    blocks are persistent (FIVE per CU since round 6: 96 registers, 30 016 bytes of LDS -- the SIMDs were half busy with
+//    four waves each, 51.5 / 42.3 / 38.3 us at two / three / four blocks) and walk the tiles with a grid stride.
 namespace fft512 {
 
 #ifdef XVEC_MFKNOCK
@@ -257,7 +258,14 @@ constexpr int kPS = 264;                    // floats per row of the power-spect
 constexpr int kLS = 40;                     // dwords put the sixteen lanes of a ds_read_b128 service group (rows r, lane quads q: 16-byte
                                             // fragments at 4 q) on sixteen distinct 4-bank windows (260 / 36: one 2-way conflict per group)
 constexpr int kMaxItems = 5;                // (filter tile, bin group) products per wave: 20 per block (the default filterbank has 18)
-constexpr int kLdsFloats = 4 * kEx * 2 + kTile * kPS + kTile * kLS + 2 * kTile + 2 * 56;
+// The power rows of a wave's SECOND pair of frames live in its own exchange region (idle from that pair's last exchange to the
+// next tile's first), its partial sums behind them; only the first pairs' eight rows have storage of their own: 30 016 bytes a
+// block, five blocks on a CU (round 6; sixteen rows of their own were 38 464 bytes, four blocks).
+constexpr int kExRow = 16;                  // floats: the rows in wave w's region start at 16 w -- with the row stride that puts the
+                                            // sixteen rows of a tile on bank offsets 0, 8, ..., 56 twice over, as one array had them
+constexpr int kExPart = 592;                // floats: the two partial sums (2 x 64 lanes x 4) behind the rows (3 x 16 + 2 x 264 = 576)
+static_assert(3 * kExRow + 2 * kPS <= kExPart && kExPart + 512 <= 2 * kEx && kExPart % 4 == 0, "layout of an exchange region");
+constexpr int kLdsFloats = 4 * kEx * 2 + (kTile / 2) * kPS + kTile * kLS + 2 * kTile + 2 * 56;
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 // A complex value is a register pair and the arithmetic below is PACKED fp32 (v_pk_add_f32 / v_pk_mul_f32 /
@@ -410,7 +418,7 @@ __device__ __forceinline__ float ldf(__amdgpu_buffer_rsrc_t r, int off) {
 }
 
 template <bool I16>     // samples: fp32, or 16-bit PCM converted on the way in ((float)s * d.in_scale)
-__global__ __launch_bounds__(256, 4) void mfcc512_kernel(const void* __restrict__ sig, int64_t n_samples, int n_frames,
+__global__ __launch_bounds__(256, 5) void mfcc512_kernel(const void* __restrict__ sig, int64_t n_samples, int n_frames,
                                                          int64_t total_frames, int n_tiles, MfccDev d,
                                                          float* __restrict__ out) {
     constexpr int ES = I16 ? 2 : 4;
@@ -418,8 +426,8 @@ __global__ __launch_bounds__(256, 4) void mfcc512_kernel(const void* __restrict_
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     c32* ex = reinterpret_cast<c32*>(smem) + wave * kEx;            // this wave's exchange region
-    float* P = smem + 4 * kEx * 2;                                  // [16][kPS] power spectra
-    float* LE = P + kTile * kPS;                                    // [16][kLS] log mel energies
+    float* P0 = smem + 4 * kEx * 2;                                 // [8][kPS] power spectra of the first pairs: row 2 wave + i
+    float* LE = P0 + (kTile / 2) * kPS;                             // [16][kLS] log mel energies
     float* en = LE + kTile * kLS;                                   // [2][16] frame energies (by tile parity)
     const int hi = lane >> 3, lo = lane & 7, q = lane >> 4, row = lane & 15;
     // the split's partner lane (holds Z[512 - k] of this lane's bins k = hi + 8 lo + 64 k2, k2 < 4) as a ds_bpermute byte address
@@ -435,26 +443,31 @@ __global__ __launch_bounds__(256, 4) void mfcc512_kernel(const void* __restrict_
     __syncthreads();
     // resident B fragments: products wave, wave + 4, ... of the list {tile 0 groups, tile 1 groups}
     const int n_items = d.f_n0 + d.f_n1;
-    f32x4v fb[kMaxItems];
     int a_off[kMaxItems];                                           // float offset of the A fragment in a P row
+    int b_off[kMaxItems];                                           // its B fragment in d.f_fb (bytes, uniform; lane l reads 16 bytes at 16 l)
+    const __amdgpu_buffer_rsrc_t fb_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.f_fb), (short)0, 32 * 64 * 16, 0x00020000);
 #pragma unroll
     for (int s = 0; s < kMaxItems; ++s) {
         const int it = wave + 4 * s;
-        fb[s] = f32x4v{0.f, 0.f, 0.f, 0.f};
         a_off[s] = 0;
+        int bo = 0;                                                 // past the list: any product, it is left out of the sums
         if (it < n_items) {
             const int t = it < d.f_n0 ? 0 : 1;
             const int g = t ? d.f_lo1 + it - d.f_n0 : d.f_lo0 + it;
-            fb[s] = reinterpret_cast<const f32x4v*>(d.f_fb)[(t * 16 + g) * 64 + lane];
+            bo = (t * 16 + g) * 64;
             a_off[s] = 16 * g;
         }
+        b_off[s] = __builtin_amdgcn_readfirstlane(bo * 16);
     }
+    // tile row r = lane & 15 (frame r of the tile) as the matrix products read it: wave r >> 2, pair (r >> 1) & 1, frame r & 1
+    const float* prow = ((row >> 1) & 1) ? smem + (row >> 2) * (2 * kEx + kExRow) + (row & 1) * kPS
+                                         : P0 + (2 * (row >> 2) + (row & 1)) * kPS;
     const int used = d.frame_len < 512 ? d.frame_len : 512;
     const float scale = 0.25f / 512.f;                              // (1/2)^2 from the split, 1/nfft from powspec
 
     // raw samples of a pair of frames (x[n] and x[n-1] of both).  Requesting them one pair ahead (during the split of
-    // the previous pair / the previous tile's matrix products) measured the same, interleaved on one box: with four
-    // waves per SIMD the memory latency is already covered, the kernel is issue-bound (VALU 50 %, LDS array 54 % busy).
+    // the previous pair / the previous tile's matrix products) measured the same, interleaved on one box, and would cost
+    // 32 registers that a fifth wave per SIMD uses better (VALU 50 %, LDS array 54 % busy at four waves).
     // (every load writes a SCALAR of its own: an asm output that is one half of a register pair goes through a temporary and a
     //  copy, which hipcc places right behind the load -- before the data has landed)
     float cur_a[8], cur_b[8], prev_a[8], prev_b[8];                 // x[n] and x[n-1] of frame A (real part) and frame B (imaginary part)
@@ -559,6 +572,8 @@ __global__ __launch_bounds__(256, 4) void mfcc512_kernel(const void* __restrict_
                 f[m].x = __int_as_float(__builtin_amdgcn_ds_bpermute(part_addr, __float_as_int(sx)));
                 f[m].y = __int_as_float(__builtin_amdgcn_ds_bpermute(part_addr, __float_as_int(sy)));
             }
+            // (second pair: into this wave's exchange region -- its last read of the region is in program order before these writes)
+            float* pw = pp ? smem + wave * (2 * kEx + kExRow) : P0 + 2 * wave * kPS;
             float ea = 0.f, eb = 0.f;
 #pragma unroll
             for (int k2 = 0; k2 < 4; ++k2) {
@@ -568,8 +583,8 @@ __global__ __launch_bounds__(256, 4) void mfcc512_kernel(const void* __restrict_
                 const c32 sa2 = cadd_conj(x[k2], z), sb2 = csub_conj(x[k2], z);   // 2A, 2iB
                 const c32 qa = sa2 * sa2, qb = sb2 * sb2;
                 const float pa = (qa.x + qa.y) * scale_a, pb = (qb.x + qb.y) * scale_b;
-                P[r0 * kPS + bin0 + 64 * k2] = pa;
-                P[(r0 + 1) * kPS + bin0 + 64 * k2] = pb;
+                pw[bin0 + 64 * k2] = pa;
+                pw[kPS + bin0 + 64 * k2] = pb;
                 ea += pa;
                 eb += pb;
             }
@@ -584,20 +599,26 @@ __global__ __launch_bounds__(256, 4) void mfcc512_kernel(const void* __restrict_
                 en[par * kTile + r0 + 1] = eb == 0.f ? kEps : eb;
             }
         }
-        __syncthreads();                                            // P and en complete
+        // the filterbank's B fragments: requested here, used behind the barrier (resident they were twenty registers of the 96
+        // that five waves per SIMD leave a lane)
+        f32x4v fb[kMaxItems];
+#pragma unroll
+        for (int s = 0; s < kMaxItems; ++s)
+            fb[s] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(fb_rs, lane * 16, b_off[s], 0));
+        __syncthreads();                                            // power rows and en complete
         if constexpr (MF_KNOCK_TAIL) continue;
         // ---- mel filterbank: this wave's share of the (filter tile, bin group) products
         // Independent accumulators, the k-steps outermost: an MFMA's accumulator is then two or three MFMAs old when the next
         // one needs it (v_mfma_f32_16x16x4_f32: 32 cycles to issue, 40 until a dependent one may start).  Round 4 chained all
         // twenty MFMAs of a wave through two accumulators: twenty waits of one MFMA's latency per tile with nothing between
         // them.  Two rounds (products 0-2, then 3-4): all five at once needs 40 registers and spills.  (Products past n_items
-        // have all-zero B fragments and read P columns that exist: they add exact zeros and are left out of the sums.)
+        // repeat product 0 and are left out of the sums.)
         f32x4v acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #define MF_FB_ROUND(S0_, N_)                                                                                       \
         {                                                                                                          \
             f32x4v pa[N_], pacc[N_];                                                                               \
             _Pragma("unroll") for (int s = 0; s < N_; ++s) {                                                       \
-                pa[s] = *reinterpret_cast<const f32x4v*>(P + row * kPS + a_off[S0_ + s] + 4 * q);                  \
+                pa[s] = *reinterpret_cast<const f32x4v*>(prow + a_off[S0_ + s] + 4 * q);                           \
                 pacc[s] = f32x4v{0.f, 0.f, 0.f, 0.f};                                                              \
             }                                                                                                      \
             _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                          \
@@ -613,12 +634,13 @@ __global__ __launch_bounds__(256, 4) void mfcc512_kernel(const void* __restrict_
         MF_FB_ROUND(0, 3)
         MF_FB_ROUND(3, 2)
 #undef MF_FB_ROUND
-        // partial sums into the wave's (now idle) exchange region
-        reinterpret_cast<f32x4v*>(ex)[lane] = acc0;
-        reinterpret_cast<f32x4v*>(ex)[64 + lane] = acc1;
+        // partial sums into the wave's exchange region, behind its two power rows (which other waves may still be reading)
+        float* part = reinterpret_cast<float*>(ex) + kExPart;
+        reinterpret_cast<f32x4v*>(part)[lane] = acc0;
+        reinterpret_cast<f32x4v*>(part)[64 + lane] = acc1;
         __syncthreads();
         if (tid < 128) {                                            // tile t = tid >> 6: sum in wave order, log
-            const f32x4v* p = reinterpret_cast<const f32x4v*>(smem) + tid;
+            const f32x4v* p = reinterpret_cast<const f32x4v*>(smem + kExPart) + tid;
             f32x4v v = p[0];
 #pragma unroll
             for (int w = 1; w < 4; ++w) v += p[w * (kEx / 2)];
@@ -647,13 +669,25 @@ __global__ __launch_bounds__(256, 4) void mfcc512_kernel(const void* __restrict_
             }
             const int c = 16 * wave + row;
             if (c < d.numcep) {
+                // (a descriptor over the tile's live frames: the range check is the test against total_frames, the lane's part one
+                //  32-bit offset -- as pointer arithmetic this was five register pairs held across the whole tile loop)
+                const int64_t left = total_frames - (int64_t)tile * kTile;
+                const int live = left < kTile ? (int)left : kTile;
+                const __amdgpu_buffer_rsrc_t o_rs = __builtin_amdgcn_make_buffer_rsrc(
+                    out + (int64_t)tile * kTile * d.numcep, (short)0, live * d.numcep * 4, 0x00020000);
+                int q4 = lane;                                      // (opaque: addresses made from it are made here, not held in
+                asm volatile("" : "+v"(q4));                        //  registers across the tile loop)
+                q4 = (q4 >> 4) * 4;
+                const int vo = (q4 * d.numcep + c) * 4;
+                if (c == 0 && d.append_energy) {                    // cepstrum 0 <- log of the frame energy
+                    const f32x4v e4 = *reinterpret_cast<const f32x4v*>(en + par * kTile + q4);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[r] = logf(e4[r]);
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int fr = 4 * q + r;
-                    const int64_t gf = (int64_t)tile * kTile + fr;
-                    float v = acc[r];
-                    if (c == 0 && d.append_energy) v = logf(en[par * kTile + fr]);
-                    if (gf < total_frames) out[gf * d.numcep + c] = v;
+                    const float v = acc[r];                         // (never bit_cast an ELEMENT of a vector: hipcc 7.2 reads element 0)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(v), o_rs, vo, r * d.numcep * 4, 0);
                 }
             }
         }
@@ -878,7 +912,7 @@ static int mfcc_run(xvec_mfcc_plan* p, const void* signal, bool i16, float in_sc
     hipStream_t hs = static_cast<hipStream_t>(stream);
     if (p->fast && total_frames < (int64_t(1) << 31) - fft512::kTile && n_samples < (int64_t(1) << 30)) {
         const int n_tiles = (int)((total_frames + fft512::kTile - 1) / fft512::kTile);
-        const int grid = std::min(n_tiles, 4 * p->num_cu);
+        const int grid = std::min(n_tiles, 5 * p->num_cu);   // five blocks of 30 016 bytes of LDS and 96 registers per CU
         dv.fr_shift = 0;
         while ((1u << dv.fr_shift) < (unsigned)n_frames) ++dv.fr_shift;
         dv.fr_magic = (unsigned)((((unsigned long long)1 << (31 + dv.fr_shift)) + n_frames - 1) / (unsigned)n_frames);

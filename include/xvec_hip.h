@@ -222,6 +222,11 @@ typedef struct {
 int xvec_mfcc_create(const xvec_mfcc_cfg* cfg, xvec_mfcc_plan** out);
 void xvec_mfcc_destroy(xvec_mfcc_plan* plan);
 const char* xvec_mfcc_last_error(void);
+/* Which kernel serves the plan (introspection for tests and benchmarks; no reference counterpart): 0 = the general kernel
+ * (nfft != 512, nfilt or numcep > 32), 1 = the nfft-512 kernel with the mel filterbank as dense 16 x 16 x 16 products,
+ * 2 = the same with the filterbank as a banded product (every bin group's filters inside a window of four; the reference's
+ * call takes this one).  -1 for a null plan.  XVEC_MFCC_FILTERBANK=dense in the environment at create time forces 1 over 2. */
+int32_t xvec_mfcc_kernel_form(const xvec_mfcc_plan* plan);
 /* frames produced for n_samples samples: 1 + ceil((n - frame_len)/frame_step), 1 if n <= frame_len */
 int32_t xvec_mfcc_frames(const xvec_mfcc_plan* plan, int64_t n_samples);
 /* signal[B, n_samples] fp32 (device) -> out[B, frames, numcep] fp32 (device) */

@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -42,6 +43,10 @@ struct MfccDev {
     const float* f_fb;      // [2 filter tiles][16 bin groups][64 lanes][4]
     const float* f_dct;     // [2 cepstrum tiles][2 filter groups][64 lanes][4]
     int f_n0, f_lo0, f_n1, f_lo1;   // bin groups with a non-zero weight: tile 0 [lo0, lo0+n0), tile 1 [lo1, lo1+n1)
+    // the filterbank as a BANDED product on v_mfma_f32_4x4x1_16b_f32 (fft512::kBand*; f_band == nullptr: the dense form)
+    const float* f_band;    // [4 waves][6][64 lanes][4]: 20 weights per lane (instruction n = 4 q + c), then 4 LDS byte offsets
+    const int* f_gat;       // [8][32]: per filter, LDS byte offsets of the partial sums that hold it (frame quad 0)
+    int f_gat_n;            // the longest list of a filter (entries past a filter's list point at zeros)
     // frame index -> (utterance, frame of the utterance) without a division: b = (g * fr_magic) >> (31 + fr_shift), exact for
     // g < 2^31 (fr_magic = ceil(2^(31 + fr_shift) / n_frames), fr_shift = ceil(log2 n_frames); set per launch by xvec_mfcc)
     unsigned fr_magic;
@@ -233,7 +238,9 @@ __global__ __launch_bounds__(kThreads) void mfcc_kernel(const void* __restrict__
 //  * a block of four waves owns 16 consecutive frames of the batch (frames are numbered through the whole batch:
 //    76 544 = 4784 x 16 for 256 x 299, no ragged last tile per utterance), two pairs per wave, and leaves their
 //    power spectra in LDS as sixteen rows of 256 (eight in an array, eight in the waves' exchange regions: kExRow);
-//  * mel filterbank and DCT x lifter are matrix products on v_mfma_f32_16x16x4_f32 (exact fp32): P[16 x 256] x
+//  * the mel filterbank is a BANDED product on v_mfma_f32_4x4x1_16b_f32 (kBand* below; round 6) and, for a filterbank that
+//    form cannot hold, the dense one described next; the DCT x lifter is dense either way.
+//  * dense: mel filterbank and DCT x lifter are matrix products on v_mfma_f32_16x16x4_f32 (exact fp32): P[16 x 256] x
 //    FB^T[256 x 32] with the filterbank's zero blocks skipped (filters 0-15 end at bin 87, filters 16-25 begin
 //    at bin 77: 18 of 32 blocks of 16 bins), split over the four waves and summed in wave order; log;
 //    [16 x 32] x DCTL^T[32 x 32].  The B fragments are packed per lane on the host and fetched per tile (L2-resident):
@@ -266,6 +273,20 @@ constexpr int kExRow = 16;                  // floats: the rows in wave w's regi
 constexpr int kExPart = 592;                // floats: the two partial sums (2 x 64 lanes x 4) behind the rows (3 x 16 + 2 x 264 = 576)
 static_assert(3 * kExRow + 2 * kPS <= kExPart && kExPart + 512 <= 2 * kEx && kExPart % 4 == 0, "layout of an exchange region");
 constexpr int kLdsFloats = 4 * kEx * 2 + (kTile / 2) * kPS + kTile * kLS + 2 * kTile + 2 * 56;
+// ---- the banded filterbank (round 6).  A bin carries weight for two neighbouring triangles, the dense form multiplies it
+// with sixteen: 18 products of 16 x 16 x 16 per tile, 32 cycles of the matrix pipe per 16 x 16 x 4 step, 640 cycles per wave
+// and tile -- a fifth of a SIMD's busy time.  v_mfma_f32_4x4x1_16b_f32 is SIXTEEN independent 4 x 4 x 1 products (8 cycles):
+// block 4 fq + s takes frames 4 fq .. + 3 (rows) of ONE bin and the bin's weights for FOUR neighbouring filters (columns).
+// The host cuts the bins into at most 15 GROUPS of at most 20 consecutive bins whose filters fit one window of four (a .. a + 3);
+// wave w owns groups 4 w .. 4 w + 3, SLOT s of its instructions is group 4 w + s, instruction n the group's bin n: 20
+// instructions of 8 cycles per wave and tile, every lane ends with a group's [4 frames] x one filter, nothing to add across
+// lanes.  The summing threads gather per filter the (at most eight) groups that hold it, in bin order; an absent entry points
+// at group 15, whose weights are all zero.
+constexpr int kBandN = 20;                  // instructions per tile and wave = bins per group
+constexpr int kBandGroups = 15;             // (+ the all-zero group 15)
+constexpr int kBandGat = 8;                 // groups a filter can collect from
+constexpr int kBandLdsFloats = kLdsFloats + kBandGat * 32;   // + the gather table
+static_assert(kBandLdsFloats * 4 <= 32 * 1024, "five blocks per CU");
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 // A complex value is a register pair and the arithmetic below is PACKED fp32 (v_pk_add_f32 / v_pk_mul_f32 /
@@ -417,12 +438,12 @@ __device__ __forceinline__ float ldf(__amdgpu_buffer_rsrc_t r, int off) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
 }
 
-template <bool I16>     // samples: fp32, or 16-bit PCM converted on the way in ((float)s * d.in_scale)
+template <bool I16, bool BAND>   // I16: 16-bit PCM samples converted on the way in ((float)s * d.in_scale); BAND: the banded filterbank
 __global__ __launch_bounds__(256, 5) void mfcc512_kernel(const void* __restrict__ sig, int64_t n_samples, int n_frames,
                                                          int64_t total_frames, int n_tiles, MfccDev d,
                                                          float* __restrict__ out) {
     constexpr int ES = I16 ? 2 : 4;
-    __shared__ __attribute__((aligned(16))) float smem[kLdsFloats];
+    __shared__ __attribute__((aligned(16))) float smem[BAND ? kBandLdsFloats : kLdsFloats];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     c32* ex = reinterpret_cast<c32*>(smem) + wave * kEx;            // this wave's exchange region
@@ -440,6 +461,13 @@ __global__ __launch_bounds__(256, 5) void mfcc512_kernel(const void* __restrict_
     for (int k = 0; k < 7; ++k) w1[k] = reinterpret_cast<const c32*>(d.f_tw1)[k * 64 + lane];
     c32* w2 = reinterpret_cast<c32*>(en + 2 * kTile);
     if (tid < 56) w2[tid] = reinterpret_cast<const c32*>(d.f_tw2)[tid];
+    int* gat = reinterpret_cast<int*>(smem + kLdsFloats);           // BAND: [kBandGat][32] byte offsets
+    if constexpr (BAND) gat[tid] = d.f_gat[tid];                    // kBandGat * 32 = 256 = the block's threads
+    const __amdgpu_buffer_rsrc_t band_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(BAND ? d.f_band : d.f_fb), (short)0,
+                                                                             (4 * 5 + 1) * 64 * 16, 0x00020000);
+    // BAND: LDS byte address of this lane's row (frame 4 fq + t) at its group's first bin
+    int band_a = 0;
+    if constexpr (BAND) band_a = __builtin_amdgcn_raw_buffer_load_b32(band_rs, lane * 4 + wave * 256, 4 * 5 * 1024, 0);
     __syncthreads();
     // resident B fragments: products wave, wave + 4, ... of the list {tile 0 groups, tile 1 groups}
     const int n_items = d.f_n0 + d.f_n1;
@@ -516,6 +544,13 @@ __global__ __launch_bounds__(256, 5) void mfcc512_kernel(const void* __restrict_
                 prev_b[a_] = __fmul_rn((float)__builtin_bit_cast(int, prev_b[a_]), d.in_scale);                          \
             }                                                                                                  \
         }                                                                                                      \
+    }
+    // BAND leaves registers free (80 of the 96 that five waves per SIMD allow): the DCT's B fragments of waves 0 and 1 stay
+    // resident (-0.3 us).  (Two or four of the five weight fragments resident as well: 39.35 / 39.34 against 39.34 us, nothing.)
+    f32x4v db_res[2] = {};
+    if constexpr (BAND) {
+        db_res[0] = reinterpret_cast<const f32x4v*>(d.f_dct)[((wave & 1) * 2 + 0) * 64 + lane];
+        db_res[1] = reinterpret_cast<const f32x4v*>(d.f_dct)[((wave & 1) * 2 + 1) * 64 + lane];
     }
     int par = 0;
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, par ^= 1) {
@@ -604,7 +639,8 @@ __global__ __launch_bounds__(256, 5) void mfcc512_kernel(const void* __restrict_
         f32x4v fb[kMaxItems];
 #pragma unroll
         for (int s = 0; s < kMaxItems; ++s)
-            fb[s] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(fb_rs, lane * 16, b_off[s], 0));
+            fb[s] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(BAND ? band_rs : fb_rs, lane * 16,
+                                                                                    BAND ? (wave * 5 + s) * 1024 : b_off[s], 0));
         __syncthreads();                                            // power rows and en complete
         if constexpr (MF_KNOCK_TAIL) continue;
         // ---- mel filterbank: this wave's share of the (filter tile, bin group) products
@@ -613,6 +649,24 @@ __global__ __launch_bounds__(256, 5) void mfcc512_kernel(const void* __restrict_
         // twenty MFMAs of a wave through two accumulators: twenty waits of one MFMA's latency per tile with nothing between
         // them.  Two rounds (products 0-2, then 3-4): all five at once needs 40 registers and spills.  (Products past n_items
         // repeat product 0 and are left out of the sums.)
+        if constexpr (BAND) {
+            // ---- banded filterbank: 20 x v_mfma_f32_4x4x1_16b_f32 into four accumulators in turn (an accumulator is four
+            // instructions old when its next one needs it), added at the end in a fixed order
+            static_assert(kMaxItems * 4 == kBandN, "20 weights per lane in five fragments");
+            f32x4v acc[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] = f32x4v{0.f, 0.f, 0.f, 0.f};
+            const char* lds = reinterpret_cast<const char*>(smem) + band_a;
+#pragma unroll
+            for (int n = 0; n < kBandN; ++n) {
+                const float av = *reinterpret_cast<const float*>(lds + 4 * n);
+                acc[n & 3] = __builtin_amdgcn_mfma_f32_4x4x1f32(av, fb[n >> 2][n & 3], acc[n & 3], 0, 0, 0);
+            }
+            const f32x4v sum = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+            int lo4 = lane;                                         // (opaque: the address below is made here, not held across the loop)
+            asm volatile("" : "+v"(lo4));
+            reinterpret_cast<f32x4v*>(reinterpret_cast<float*>(ex) + kExPart)[lo4] = sum;   // [frame quad][group][filter] x 4 frames
+        } else {
         f32x4v acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #define MF_FB_ROUND(S0_, N_)                                                                                       \
         {                                                                                                          \
@@ -638,8 +692,29 @@ __global__ __launch_bounds__(256, 5) void mfcc512_kernel(const void* __restrict_
         float* part = reinterpret_cast<float*>(ex) + kExPart;
         reinterpret_cast<f32x4v*>(part)[lane] = acc0;
         reinterpret_cast<f32x4v*>(part)[64 + lane] = acc1;
+        }
         __syncthreads();
-        if (tid < 128) {                                            // tile t = tid >> 6: sum in wave order, log
+        if constexpr (BAND) {
+            if (tid < 128) {                                        // frames 4 fq .. + 3 of filter f: its groups in bin order, log
+                const int f = tid & 31, fq64 = (tid >> 5) * 256;
+                static_assert(kBandGat == 8, "two halves of four");
+                int off[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) off[e] = gat[e * 32 + f];
+                const char* lds = reinterpret_cast<const char*>(smem) + fq64;
+                f32x4v v = *reinterpret_cast<const f32x4v*>(lds + off[0]);
+#pragma unroll
+                for (int e = 1; e < 4; ++e) v += *reinterpret_cast<const f32x4v*>(lds + off[e]);
+                if (d.f_gat_n > 4) {                                // (uniform; the reference's filterbank: four at most)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) off[e] = gat[(4 + e) * 32 + f];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v += *reinterpret_cast<const f32x4v*>(lds + off[e]);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) LE[((tid >> 5) * 4 + r) * kLS + f] = logf(v[r] == 0.f ? kEps : v[r]);
+            }
+        } else if (tid < 128) {                                            // tile t = tid >> 6: sum in wave order, log
             const f32x4v* p = reinterpret_cast<const f32x4v*>(smem + kExPart) + tid;
             f32x4v v = p[0];
 #pragma unroll
@@ -656,6 +731,9 @@ __global__ __launch_bounds__(256, 5) void mfcc512_kernel(const void* __restrict_
                 db[0] = f32x4v{1.f, 0.5f, 0.25f, 2.f};
                 db[1] = db[0];
                 asm volatile("" : "+v"(db[0]), "+v"(db[1]));
+            } else if constexpr (BAND) {                            // (the banded form leaves the registers to keep them)
+                db[0] = db_res[0];
+                db[1] = db_res[1];
             } else {
                 db[0] = reinterpret_cast<const f32x4v*>(d.f_dct)[(wave * 2 + 0) * 64 + lane];
                 db[1] = reinterpret_cast<const f32x4v*>(d.f_dct)[(wave * 2 + 1) * 64 + lane];
@@ -807,7 +885,7 @@ int xvec_mfcc_create(const xvec_mfcc_cfg* cfg, xvec_mfcc_plan** out) {
     if (blob.size() & 1) blob.push_back(0.f);            // keep the per-wave regions 8-byte aligned
     p->dev.table_floats = (int)blob.size();
     // tables of the nfft == 512 kernel, after the LDS image (16-byte aligned)
-    int f_tw1 = 0, f_tw2 = 0, f_fb = 0, f_dct = 0;
+    int f_tw1 = 0, f_tw2 = 0, f_fb = 0, f_dct = 0, f_band = -1, f_gat = 0;
     p->fast = (nfft == 512 && nfilt <= 32 && numcep <= 32);
     if (p->fast) {
         while (blob.size() & 3) blob.push_back(0.f);
@@ -857,6 +935,84 @@ int xvec_mfcc_create(const xvec_mfcc_cfg* cfg, xvec_mfcc_plan** out) {
                         const int c = 16 * t + (l & 15), m = 16 * g + 4 * (l >> 4) + j;
                         blob.push_back(c < numcep && m < nfilt ? dctl[(size_t)c * dct_ld + m] : 0.f);
                     }
+        // ---- the banded form (fft512::kBand*): groups of consecutive bins whose filters fit a window of four
+        {
+            using namespace fft512;
+            int fmin[256], fmax[256];
+            for (int k = 0; k < 256; ++k) {
+                fmin[k] = 32;
+                fmax[k] = -1;
+                for (int j = 0; j < 32; ++j)
+                    if (dense[j * 256 + k] != 0.f) {
+                        fmin[k] = std::min(fmin[k], j);
+                        fmax[k] = std::max(fmax[k], j);
+                    }
+            }
+            int g_k[16] = {}, g_cnt[16] = {}, g_a[16] = {}, n_groups = 0;   // (group 15 stays empty: all-zero weights)
+            bool ok = true;
+            for (int k = 0; k < 256 && ok;) {
+                if (n_groups == kBandGroups) { ok = false; break; }
+                int a = -1, cnt = 0;
+                const int k0 = k;
+                while (k < 256 && cnt < kBandN) {
+                    if (fmax[k] >= 0) {                            // (a bin without weight joins any group)
+                        if (a < 0) a = std::min(fmin[k], 28);
+                        if (fmax[k] > a + 3) break;
+                    }
+                    ++k;
+                    ++cnt;
+                }
+                if (cnt == 0) { ok = false; break; }               // one bin wider than a window
+                g_k[n_groups] = k0;
+                g_cnt[n_groups] = cnt;
+                g_a[n_groups++] = a < 0 ? 0 : a;
+            }
+            // where the partial sums of group g, frame quad 0, filter column j sit (bytes from the start of the block's LDS):
+            // wave g >> 2 writes lane 16 fq + 4 (g & 3) + j
+            auto part_byte = [&](int g, int j) { return ((g >> 2) * 2 * kEx + kExPart) * 4 + ((g & 3) * 4 + j) * 16; };
+            std::vector<int> gat(kBandGat * 32, part_byte(15, 0));  // absent: a column of the all-zero group
+            int gat_n = 0;
+            for (int f = 0; f < 32 && ok; ++f) {
+                int e = 0;
+                for (int g = 0; g < n_groups; ++g) {
+                    if (f < g_a[g] || f > g_a[g] + 3) continue;
+                    bool any = false;
+                    for (int k = g_k[g]; k < g_k[g] + g_cnt[g]; ++k) any = any || dense[f * 256 + k] != 0.f;
+                    if (!any) continue;
+                    if (e == kBandGat) { ok = false; break; }
+                    gat[e++ * 32 + f] = part_byte(g, f - g_a[g]);
+                }
+                gat_n = std::max(gat_n, e);
+            }
+            p->dev.f_gat_n = gat_n;
+            // (XVEC_MFCC_FILTERBANK=dense keeps the dense products for a filterbank the banded form can hold: tests and A/B timing)
+            const char* force = getenv("XVEC_MFCC_FILTERBANK");
+            if (force && strcmp(force, "dense") == 0) ok = false;
+            if (ok) {
+                while (blob.size() & 3) blob.push_back(0.f);
+                f_band = (int)blob.size();
+                // first bin a group's lanes read (the reads of a short group stay inside the row: its first bins then carry weight 0)
+                auto k_read = [&](int g) { return g < n_groups ? std::min(g_k[g], 256 - kBandN) : 0; };
+                for (int w = 0; w < 4; ++w)
+                    for (int q5 = 0; q5 < 5; ++q5)
+                        for (int l = 0; l < 64; ++l)
+                            for (int c = 0; c < 4; ++c) {          // weight of instruction n = 4 q5 + c: bin n of group 4 w + slot
+                                const int g = 4 * w + ((l >> 2) & 3), t = l & 3, kk = k_read(g) + 4 * q5 + c;
+                                const bool live = g < n_groups && kk >= g_k[g] && kk < g_k[g] + g_cnt[g];
+                                blob.push_back(live ? dense[(g_a[g] + t) * 256 + kk] : 0.f);
+                            }
+                for (int w = 0; w < 4; ++w)                        // LDS byte address of frame 4 fq + t at the group's first bin
+                    for (int l = 0; l < 64; ++l) {
+                        const int fq = l >> 4, g = 4 * w + ((l >> 2) & 3), t = l & 3;
+                        const int rowf = (t >> 1) ? fq * (2 * kEx + kExRow) + (t & 1) * kPS : 4 * kEx * 2 + (2 * fq + (t & 1)) * kPS;
+                        const int byte = (rowf + k_read(g)) * 4;
+                        float fv;
+                        memcpy(&fv, &byte, 4);
+                        blob.push_back(fv);
+                    }
+                f_gat = app_i(gat);
+            }
+        }
     }
     if (hipMalloc(&p->blob, blob.size() * 4) != hipSuccess) {
         delete p;
@@ -872,6 +1028,8 @@ int xvec_mfcc_create(const xvec_mfcc_cfg* cfg, xvec_mfcc_plan** out) {
     p->dev.f_tw2 = p->dev.tables + f_tw2;
     p->dev.f_fb = p->dev.tables + f_fb;
     p->dev.f_dct = p->dev.tables + f_dct;
+    p->dev.f_band = f_band >= 0 ? p->dev.tables + f_band : nullptr;
+    p->dev.f_gat = reinterpret_cast<const int*>(p->dev.tables + f_gat);
     p->dev.frame_len = frame_len;
     p->dev.frame_step = frame_step;
     p->dev.nfft = nfft;
@@ -895,6 +1053,11 @@ void xvec_mfcc_destroy(xvec_mfcc_plan* p) {
     delete p;
 }
 
+int32_t xvec_mfcc_kernel_form(const xvec_mfcc_plan* p) {
+    if (!p) return -1;
+    return !p->fast ? 0 : p->dev.f_band == nullptr ? 1 : 2;
+}
+
 int32_t xvec_mfcc_frames(const xvec_mfcc_plan* p, int64_t n_samples) {
     if (!p || n_samples < 1) return 0;
     if (n_samples <= p->dev.frame_len) return 1;
@@ -916,8 +1079,11 @@ static int mfcc_run(xvec_mfcc_plan* p, const void* signal, bool i16, float in_sc
         dv.fr_shift = 0;
         while ((1u << dv.fr_shift) < (unsigned)n_frames) ++dv.fr_shift;
         dv.fr_magic = (unsigned)((((unsigned long long)1 << (31 + dv.fr_shift)) + n_frames - 1) / (unsigned)n_frames);
-        if (i16) fft512::mfcc512_kernel<true><<<grid, 256, 0, hs>>>(signal, n_samples, n_frames, total_frames, n_tiles, dv, out);
-        else fft512::mfcc512_kernel<false><<<grid, 256, 0, hs>>>(signal, n_samples, n_frames, total_frames, n_tiles, dv, out);
+        const bool band = dv.f_band != nullptr;                 // (else: a filterbank the banded form cannot hold; the dense products)
+        if (i16 && band) fft512::mfcc512_kernel<true, true><<<grid, 256, 0, hs>>>(signal, n_samples, n_frames, total_frames, n_tiles, dv, out);
+        else if (i16) fft512::mfcc512_kernel<true, false><<<grid, 256, 0, hs>>>(signal, n_samples, n_frames, total_frames, n_tiles, dv, out);
+        else if (band) fft512::mfcc512_kernel<false, true><<<grid, 256, 0, hs>>>(signal, n_samples, n_frames, total_frames, n_tiles, dv, out);
+        else fft512::mfcc512_kernel<false, false><<<grid, 256, 0, hs>>>(signal, n_samples, n_frames, total_frames, n_tiles, dv, out);
         if (hipGetLastError() != hipSuccess) return mfail(XVEC_ERR_HIP, "mfcc kernel launch failed");
         return XVEC_OK;
     }

@@ -42,6 +42,11 @@ class MfccFrontEnd:
             except Exception:
                 pass
 
+    def kernel_form(self) -> int:
+        """0: the general kernel; 1: the nfft-512 kernel, dense filterbank products; 2: the same, banded filterbank
+        (xvec_mfcc_kernel_form; what tests and benchmarks name the measured kernel by)."""
+        return int(_hip.lib.xvec_mfcc_kernel_form(self._plan))
+
     def num_frames(self, n_samples: int) -> int:
         return int(_hip.lib.xvec_mfcc_frames(self._plan, n_samples))
 

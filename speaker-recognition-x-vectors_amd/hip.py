@@ -92,6 +92,7 @@ _SIGS = {
     "xvec_mfcc_destroy": (None, [_vp]),
     "xvec_mfcc_last_error": (C.c_char_p, []),
     "xvec_mfcc_frames": (C.c_int32, [_vp, _i64]),
+    "xvec_mfcc_kernel_form": (C.c_int32, [_vp]),
     "xvec_mfcc": (C.c_int, [_vp, _f32p, _i32, _i64, _f32p, _vp]),
     "xvec_mfcc_i16": (C.c_int, [_vp, _vp, C.c_float, _i32, _i64, _f32p, _vp]),
     # include/xvec_score.h

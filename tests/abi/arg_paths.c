@@ -79,6 +79,7 @@ int main(void) {
         EXPECT(xvec_mfcc(0, buf, 1, 16000, buf, 0) == XVEC_ERR_ARG);
         EXPECT(xvec_mfcc_i16(0, (const int16_t*)buf, 1.0f, 1, 16000, buf, 0) == XVEC_ERR_ARG);
         EXPECT(xvec_mfcc_frames(0, 16000) <= 0);
+        EXPECT(xvec_mfcc_kernel_form(0) == -1);
         xvec_mfcc_destroy(0);
         EXPECT(strlen(xvec_mfcc_last_error()) > 0);
     }

@@ -231,3 +231,46 @@ def test_first_frame_previous_samples():
         got16 = fe(pcm, scale=1.0 / 8000).cpu().numpy()
         ref16 = np.stack([mo.mfcc(w, 16000, numcep=24, nfilt=26, nfft=512) for w in (pcm.float() / 8000).cpu().numpy()])
         assert_parity(got16[:, :3], ref16[:, :3], 1e-4, f"first frames, 16-bit PCM, variant {variant}", elem_tol=1e-3)
+
+
+@pytest.mark.gpu
+def test_kernel_form_of_a_plan():
+    """xvec_mfcc_kernel_form: the reference's call (dataset.py:128) takes the nfft-512 kernel with the BANDED filterbank (2),
+    nfft != 512 or more than 32 filters the general kernel (0); a silent fall back of the reference's configuration to a slower
+    form would otherwise only show in the bench line."""
+    import xvector_amd as xa
+    assert xa.MfccFrontEnd().kernel_form() == 2
+    assert xa.MfccFrontEnd(nfft=1024).kernel_form() == 0
+    assert xa.MfccFrontEnd(nfft=512, nfilt=40, numcep=20).kernel_form() == 0
+    assert xa.MfccFrontEnd(nfft=512, appendEnergy=False, ceplifter=0, preemph=0.0).kernel_form() == 2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", [dict(), dict(nfft=512, nfilt=20, numcep=13, lowfreq=300, highfreq=3400), dict(nfft=512, winlen=0.04),
+                                dict(nfft=512, nfilt=32, numcep=32)])
+def test_dense_and_banded_filterbank_agree(kw, monkeypatch):
+    """The nfft-512 kernel has the mel filterbank in two forms: banded 4 x 4 x 1 products (v_mfma_f32_4x4x1_16b_f32, bins in
+    groups whose filters fit a window of four) and, for a filterbank the grouping cannot hold, dense 16 x 16 x 16 products.
+    XVEC_MFCC_FILTERBANK=dense (read at create time) forces the second: both against the oracle, and against each other far
+    inside the bar -- the same weights in another summation order."""
+    import xvector_amd as xa
+    from conftest import assert_parity
+    waves = np.stack([_speechlike(20000, 170 + i) * (0.2 + 0.4 * i) for i in range(3)])
+    w = torch.from_numpy(waves).to("cuda:0")
+    fe_auto = xa.MfccFrontEnd(**kw)
+    monkeypatch.setenv("XVEC_MFCC_FILTERBANK", "dense")
+    fe_dense = xa.MfccFrontEnd(**kw)
+    monkeypatch.delenv("XVEC_MFCC_FILTERBANK")
+    assert fe_dense.kernel_form() == 1 and fe_auto.kernel_form() in (1, 2)
+    if not kw:
+        assert fe_auto.kernel_form() == 2
+    ref = np.stack([mo.mfcc(x, 16000, **{"numcep": 24, "nfilt": 26, "nfft": 512, **kw}) for x in waves])
+    got_a, got_d = fe_auto(w).cpu().numpy(), fe_dense(w).cpu().numpy()
+    assert_parity(got_a, ref, 1e-4, f"mfcc {kw}, form {fe_auto.kernel_form()}", elem_tol=1e-3)
+    assert_parity(got_d, ref, 1e-4, f"mfcc {kw}, dense filterbank", elem_tol=1e-3)
+    assert_parity(got_a, got_d, 2e-6, f"mfcc {kw}: banded against dense", elem_tol=1e-4)
+    # 16-bit PCM through the same form: bit for bit the float path (one instantiation per form)
+    pcm = (torch.from_numpy(waves) * 20000).round().clamp(-32768, 32767).to(torch.int16).to("cuda:0")
+    assert torch.equal(fe_auto(pcm, scale=1.0 / 20000), fe_auto(pcm.float() * (1.0 / 20000)))
+    assert torch.equal(fe_dense(pcm, scale=1.0 / 20000), fe_dense(pcm.float() * (1.0 / 20000)))
+

@@ -268,10 +268,11 @@ constexpr int kMaxItems = 5;                // (filter tile, bin group) products
 // The power rows of a wave's SECOND pair of frames live in its own exchange region (idle from that pair's last exchange to the
 // next tile's first), its partial sums behind them; only the first pairs' eight rows have storage of their own: 30 016 bytes a
 // block, five blocks on a CU (round 6; sixteen rows of their own were 38 464 bytes, four blocks).
-constexpr int kExRow = 16;                  // floats: the rows in wave w's region start at 16 w -- with the row stride that puts the
-                                            // sixteen rows of a tile on bank offsets 0, 8, ..., 56 twice over, as one array had them
-constexpr int kExPart = 592;                // floats: the two partial sums (2 x 64 lanes x 4) behind the rows (3 x 16 + 2 x 264 = 576)
-static_assert(3 * kExRow + 2 * kPS <= kExPart && kExPart + 512 <= 2 * kEx && kExPart % 4 == 0, "layout of an exchange region");
+constexpr int kExRow = 16;                  // floats: the rows in wave w's region start at 16 w + 4: with the row stride (8 mod 64) the
+constexpr int kExRow0 = 4;                  // eight rows of the array sit on bank offsets 0, 8, ..., 56 and these eight on 4, 12, ..., 60
+constexpr int kExPart = 592;                // floats: the partial sums (2 x 64 lanes x 4) behind the rows (3 x 16 + 4 + 2 x 264 = 580)
+static_assert(3 * kExRow + kExRow0 + 2 * kPS <= kExPart && kExPart + 512 <= 2 * kEx && kExPart % 4 == 0 && kExRow0 % 4 == 0,
+              "layout of an exchange region");
 constexpr int kLdsFloats = 4 * kEx * 2 + (kTile / 2) * kPS + kTile * kLS + 2 * kTile + 2 * 56;
 // ---- the banded filterbank (round 6).  A bin carries weight for two neighbouring triangles, the dense form multiplies it
 // with sixteen: 18 products of 16 x 16 x 16 per tile, 32 cycles of the matrix pipe per 16 x 16 x 4 step, 640 cycles per wave
@@ -282,7 +283,10 @@ constexpr int kLdsFloats = 4 * kEx * 2 + (kTile / 2) * kPS + kTile * kLS + 2 * k
 // instructions of 8 cycles per wave and tile, every lane ends with a group's [4 frames] x one filter, nothing to add across
 // lanes.  The summing threads gather per filter the (at most eight) groups that hold it, in bin order; an absent entry points
 // at group 15, whose weights are all zero.
-constexpr int kBandN = 20;                  // instructions per tile and wave = bins per group
+constexpr int kBandN = 20;                  // instructions per tile and wave = bins a group's lanes read
+constexpr int kBandCap = 19;                // bins of a group that may carry weight: one bin of play, so that the four groups of a wave
+                                            // can start their reads on four different residues mod 4 -- with the sixteen rows on bank
+                                            // offsets 0, 4, ..., 60 the 64 lanes of a read then fall on 64 different banks
 constexpr int kBandGroups = 15;             // (+ the all-zero group 15)
 constexpr int kBandGat = 8;                 // groups a filter can collect from
 constexpr int kBandLdsFloats = kLdsFloats + kBandGat * 32;   // + the gather table
@@ -488,7 +492,7 @@ __global__ __launch_bounds__(256, 5) void mfcc512_kernel(const void* __restrict_
         b_off[s] = __builtin_amdgcn_readfirstlane(bo * 16);
     }
     // tile row r = lane & 15 (frame r of the tile) as the matrix products read it: wave r >> 2, pair (r >> 1) & 1, frame r & 1
-    const float* prow = ((row >> 1) & 1) ? smem + (row >> 2) * (2 * kEx + kExRow) + (row & 1) * kPS
+    const float* prow = ((row >> 1) & 1) ? smem + (row >> 2) * (2 * kEx + kExRow) + kExRow0 + (row & 1) * kPS
                                          : P0 + (2 * (row >> 2) + (row & 1)) * kPS;
     const int used = d.frame_len < 512 ? d.frame_len : 512;
     const float scale = 0.25f / 512.f;                              // (1/2)^2 from the split, 1/nfft from powspec
@@ -608,7 +612,7 @@ __global__ __launch_bounds__(256, 5) void mfcc512_kernel(const void* __restrict_
                 f[m].y = __int_as_float(__builtin_amdgcn_ds_bpermute(part_addr, __float_as_int(sy)));
             }
             // (second pair: into this wave's exchange region -- its last read of the region is in program order before these writes)
-            float* pw = pp ? smem + wave * (2 * kEx + kExRow) : P0 + 2 * wave * kPS;
+            float* pw = pp ? smem + wave * (2 * kEx + kExRow) + kExRow0 : P0 + 2 * wave * kPS;
             float ea = 0.f, eb = 0.f;
 #pragma unroll
             for (int k2 = 0; k2 < 4; ++k2) {
@@ -954,7 +958,7 @@ int xvec_mfcc_create(const xvec_mfcc_cfg* cfg, xvec_mfcc_plan** out) {
                 if (n_groups == kBandGroups) { ok = false; break; }
                 int a = -1, cnt = 0;
                 const int k0 = k;
-                while (k < 256 && cnt < kBandN) {
+                while (k < 256 && cnt < kBandCap) {
                     if (fmax[k] >= 0) {                            // (a bin without weight joins any group)
                         if (a < 0) a = std::min(fmin[k], 28);
                         if (fmax[k] > a + 3) break;
@@ -991,8 +995,23 @@ int xvec_mfcc_create(const xvec_mfcc_cfg* cfg, xvec_mfcc_plan** out) {
             if (ok) {
                 while (blob.size() & 3) blob.push_back(0.f);
                 f_band = (int)blob.size();
-                // first bin a group's lanes read (the reads of a short group stay inside the row: its first bins then carry weight 0)
-                auto k_read = [&](int g) { return g < n_groups ? std::min(g_k[g], 256 - kBandN) : 0; };
+                // first bin a group's lanes read: anywhere in [k + cnt - 20, k] (bins in front of the group carry weight 0), inside
+                // the row, and -- where that leaves a choice -- on a residue mod 4 no earlier group of the wave reads on
+                int k_rd[16];
+                for (int w = 0; w < 4; ++w) {
+                    bool used[4] = {false, false, false, false};
+                    for (int sl = 0; sl < 4; ++sl) {
+                        const int g = 4 * w + sl;
+                        const int hi_k = g < n_groups ? std::min(g_k[g], 256 - kBandN) : 256 - kBandN;
+                        const int lo_k = g < n_groups ? std::max(0, g_k[g] + g_cnt[g] - kBandN) : 0;
+                        int pick = hi_k;
+                        for (int kk = hi_k; kk >= lo_k; --kk)
+                            if (!used[kk & 3]) { pick = kk; break; }
+                        used[pick & 3] = true;
+                        k_rd[g] = pick;
+                    }
+                }
+                auto k_read = [&](int g) { return k_rd[g]; };
                 for (int w = 0; w < 4; ++w)
                     for (int q5 = 0; q5 < 5; ++q5)
                         for (int l = 0; l < 64; ++l)
@@ -1004,7 +1023,7 @@ int xvec_mfcc_create(const xvec_mfcc_cfg* cfg, xvec_mfcc_plan** out) {
                 for (int w = 0; w < 4; ++w)                        // LDS byte address of frame 4 fq + t at the group's first bin
                     for (int l = 0; l < 64; ++l) {
                         const int fq = l >> 4, g = 4 * w + ((l >> 2) & 3), t = l & 3;
-                        const int rowf = (t >> 1) ? fq * (2 * kEx + kExRow) + (t & 1) * kPS : 4 * kEx * 2 + (2 * fq + (t & 1)) * kPS;
+                        const int rowf = (t >> 1) ? fq * (2 * kEx + kExRow) + kExRow0 + (t & 1) * kPS : 4 * kEx * 2 + (2 * fq + (t & 1)) * kPS;
                         const int byte = (rowf + k_read(g)) * 4;
                         float fv;
                         memcpy(&fv, &byte, 4);

@@ -107,9 +107,12 @@ def test_mfcc_sample_loads_are_waited_for_before_any_use():
     for body in re.split(r"\n(?=_ZN\S*mfcc512_kernel\S*:)", out.stdout)[1:]:
         name = body.split(":", 1)[0]
         pending = None                       # destination registers of the burst in flight
+        in_asm = False                       # (loads hipcc emits itself -- table fetches -- are tracked by its own wait counts)
         for line in body.split("s_endpgm")[0].splitlines():
+            if "#ASMSTART" in line or "#ASMEND" in line:
+                in_asm = "#ASMSTART" in line
             ins = line.split(";")[0].strip()
-            m = re.match(r"buffer_load_(?:dword|sshort) (v\d+), (v\d+),", ins)
+            m = re.match(r"buffer_load_(?:dword|sshort) (v\d+), (v\d+),", ins) if in_asm else None
             if m:
                 pending = set() if pending is None else pending
                 assert m.group(2) not in pending, f"{name}: {ins!r} takes its address from a register a load in flight fills"
@@ -125,4 +128,4 @@ def test_mfcc_sample_loads_are_waited_for_before_any_use():
             for lo, hi in re.findall(r"v\[(\d+):(\d+)\]", ins):
                 used |= {f"v{i}" for i in range(int(lo), int(hi) + 1)}
             assert not (used & pending), f"{name}: {ins!r} touches {sorted(used & pending)} before the loads have been waited for"
-    assert bursts >= 2                       # one request site per kernel (fp32 samples, 16-bit PCM)
+    assert bursts >= 4                       # one request site per kernel (fp32 samples | 16-bit PCM, banded | dense filterbank)

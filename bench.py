@@ -544,6 +544,8 @@ def main():
         del m16w
         secondary["mfcc_us_per_batch"] = round(timed(lambda: fe2(wv), 50, 0.05) * 1e6, 2)
         secondary["mfcc_algorithmic_gb_per_s"] = round(B * (48000 * 4 + 299 * 24 * 4) / (secondary["mfcc_us_per_batch"] * 1e-6) / 1e9, 1)
+        # which kernel that was (xvec_mfcc_kernel_form): 2 = nfft-512 kernel with the banded filterbank, 1 = its dense form, 0 = general
+        secondary["mfcc_kernel_form"] = fe2.kernel_form()
         n_sc = 4874                                                    # VoxCeleb1 test set (plda_score_stat.py:19-20: every x-vector against every other)
         mean, F, Sigma = xa.synth.make_plda(512, 200, seed=21)
         scorer = xa.scoring.PldaScorer(mean, F, Sigma, device=dev)

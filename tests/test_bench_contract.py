@@ -53,6 +53,7 @@ def test_bench_line(extra):
         assert cfg["ragged_bf16_utt_per_s"] > cfg["ragged_utt_per_s"] and cfg["job100k_bf16_embeddings_per_s"] > cfg["job100k_embeddings_per_s"]
         assert cfg["plda_score_ms_n4874"] < cfg["plda_dense_score_ms_n4874"]          # rank 200 of 512
         assert cfg["wave_bf16_utt_per_s"] > cfg["wave_utt_per_s"] and cfg["mfcc_us_per_batch"] < 500 and cfg["plda_score_ms_n4874"] < 20
+        assert cfg["mfcc_kernel_form"] == 2          # the reference's MFCC call runs the nfft-512 kernel with the banded filterbank
     else:
         assert "bf16_embeddings_per_s" not in cfg
 

@@ -21,12 +21,13 @@ nxt = out.get("next_rows")
 if nxt:
     n, dim, R = 4874, 512, 200             # the PLDA model of next_rows_pmc.py: rank 200 of 512, the low-rank scorer (round 6)
     alg = {"mfcc512_kernel": 256 * (48000 * 4 + 299 * 24 * 4),              # 256 waveforms of 3 s in, [256, 299, 24] out
-           # the [n, n] score matrix over the upper triangle of tiles: y W and y in (K = R), every score out
-           "gemm_nt_f64_kernel<true, 4, false> [grid 512]": (2 * n * R + n * n) * 8,
+           # the [n, n] score matrix over the upper triangle of tiles: y W and y in (K = R), every score out (64 x 64 tiles, four
+           # blocks per CU, at this size since round 6: 780 tiles of 128 x 128 fill 512 block slots one and a half times)
+           "gemm_nt_f64_kernel<true, 2, false> [grid 1024]": (2 * n * R + n * n) * 8,
            # y = (x - mean) L: x and L^T in, y out (77 x 4 tiles of 64 x 64)
            "gemm_nt_f64_kernel<true, 2, true> [grid 308]": (n * dim + R * dim + n * R) * 8,
            # [y W | row dots of y (-Z) with y]: y and the stacked [2 R, R] matrices in, y W and seven partials per row out
-           "gemm_nt_f64_kernel<true, 2, true> [grid 512]": (n * R + 2 * R * R + n * R + 7 * n) * 8}
+           "gemm_nt_f64_kernel<true, 2, true> [grid 539]": (n * R + 2 * R * R + n * R + 7 * n) * 8}
     for key, ent in nxt.items():
         for frag, b in alg.items():
             if isinstance(ent, dict) and frag in key:

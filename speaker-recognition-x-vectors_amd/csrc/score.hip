@@ -2,6 +2,7 @@
 //   reference: plda_classifier.py:81-87 (fast_PLDA_scoring of speechbrain 0.5.12, numpy float64)
 // C ABI: include/xvec_score.h.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 #include <algorithm>
 #include <cstdarg>
@@ -17,9 +18,8 @@ namespace {
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 
-// block tile = (32 WT) x (32 WT) of C: WT = 4 (128 x 128, the score matrix) or 2 (64 x 64: products whose 128 x 128 tiles would not
-// give every block slot of the chip at least a tile and a half -- the two [n, 512] x [512, 512] products in front of a PLDA score
-// matrix are 312 such tiles for 512 slots, and ran at 55 % of the score matrix's rate)
+// block tile = (32 WT) x (32 WT) of C: WT = 4 (128 x 128, two blocks per CU) or 2 (64 x 64, four blocks per CU); gemm_nt() picks by how
+// full the chip's last round of tiles is (the two preludes of a PLDA score matrix always take 64 x 64)
 constexpr int kSK = 16;    // K chunk: 16 doubles = one 128-byte row = eight 16-byte pairs (k = 2c, 2c+1 in pair c)
 constexpr int kSLD = 16;   // LDS row stride in doubles: 128 B, no padding.  Pair c of row r sits at position c ^ ((r >> 1) & 7)
                            // (the swizzle of tdnn_pp16.hip): a ds_read_b128 service group -- 16 lanes on 16 different rows,
@@ -391,16 +391,23 @@ int gemm_nt(const double* A, int64_t lda, const double* B, int64_t ldb, int64_t 
     }
     const bool sym = ex && ex->sym, pre = ex && ex->pre;
     if (sym && M != N) return sfail(XVEC_ERR_ARG, "symmetric walk needs a square score matrix");
-    // 128 x 128 tiles unless they would leave the chip's block slots under a tile and a half each: then 64 x 64
-    // (a symmetric walk visits only the tiles on or above the diagonal)
-    const int64_t slots = 2 * (int64_t)num_cu;
+    // Two tilings (a symmetric walk visits only the tiles on or above the diagonal):
+    //   128 x 128, two blocks per CU (255 registers);  64 x 64, FOUR blocks per CU (121 registers, 32 KiB of LDS each).
+    // Per CU the two finish the same work in the same time within a few per cent (a round of four 64 x 64 tiles against a round
+    // of two 128 x 128 ones: 0.49 for K <= 256, 0.53 for longer K, measured N = 1200 ... 16384, profiles/experiments/README.md), and
+    // a block slot walks ceil(tiles / slots) tiles -- so what decides is how full the LAST round is.  The reference's self-score
+    // of 4874 vectors is 780 tiles of 128 x 128 on 512 slots (two rounds, the second half empty) against 3003 of 64 x 64 on 1024
+    // (three rounds): 0.261 -> 0.200 ms in the low-rank form, 0.487 -> 0.411 dense (round 6; until then the 64 x 64 kernel ran two
+    // blocks per CU and served only products under a tile and a half per slot).
+    const int64_t slots128 = 2 * (int64_t)num_cu, slots64 = 4 * (int64_t)num_cu;
     auto count = [&](int64_t ts) {
         const int64_t tm = (M + ts - 1) / ts, tn = (N + ts - 1) / ts;
         return sym ? tm * (tm + 1) / 2 : tm * tn;
     };
     // (the prelude product stays on 64 x 64 tiles at every size: with the centring and the row dots on top, the 128 x 128 form
     //  needs more registers than it has)
-    const bool small = pre || count(128) * 2 < 3 * slots;
+    const int64_t r128 = (count(128) + slots128 - 1) / slots128, r64 = (count(64) + slots64 - 1) / slots64;
+    const bool small = pre || count(128) * 2 < 3 * slots128 || r64 * (K <= 256 ? 49 : 53) < r128 * 100;
     const int ts = small ? 64 : 128;
     const int64_t tm = (M + ts - 1) / ts, tn = (N + ts - 1) / ts;
     const int64_t n_tiles = count(ts);
@@ -422,7 +429,7 @@ int gemm_nt(const double* A, int64_t lda, const double* B, int64_t ldb, int64_t 
             if (ex->parts_out) *ex->parts_out = parts;
         }
     }
-    const unsigned grid = (unsigned)std::min<int64_t>(n_tiles, slots);
+    const unsigned grid = (unsigned)std::min<int64_t>(n_tiles, small ? slots64 : slots128);
     const size_t lds = (size_t)2 * (ts + ts) * kSLD * sizeof(double);
     const bool vec = (K % 2 == 0) && (lda % 2 == 0) && (ldb % 2 == 0) && (reinterpret_cast<uintptr_t>(A) % 16 == 0) &&
                      (reinterpret_cast<uintptr_t>(B) % 16 == 0);

@@ -84,10 +84,12 @@ def _rel(a, b):
 
 
 @pytest.mark.gpu
-# the last two shapes are large enough for the 128 x 128 tiles (>= 768 of them) and their supertile walk, with ragged
-# last bands / supertiles (29 x 28 and 45 x 18 tiles); the others run on the 64 x 64 variant
+# the last two shapes take the 128 x 128 tiles (812 / 810 of them, two rounds of the 512 block slots, against four rounds of the
+# 1024 slots of the 64 x 64 tiles: at K > 256 a round of those counts 0.53, gemm_nt's rule) and their supertile walk, with ragged
+# last bands / supertiles (29 x 28 and 45 x 18 tiles; even K the 16-byte loads, odd K the 8-byte ones); the same shapes at short K
+# and the others run on the 64 x 64 variant, four blocks per CU
 @pytest.mark.parametrize("M,N,K", [(1, 1, 1), (3, 5, 7), (128, 128, 16), (129, 127, 33), (200, 300, 512), (64, 1000, 150),
-                                   (3601, 3500, 48), (5700, 2300, 17)])
+                                   (3601, 3500, 48), (5700, 2300, 17), (3601, 3500, 272), (5700, 2300, 257)])
 def test_gemm_nt_f64_vs_numpy(M, N, K):
     from xvector_amd import scoring
     rng = np.random.default_rng(M * 1000 + N)
@@ -190,26 +192,30 @@ def test_cosine_vs_oracle():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("lowrank", [True, False])
-def test_full_size_properties(lowrank):
+@pytest.mark.parametrize("n", [4874, 5600])
+def test_full_size_properties(lowrank, n):
     """VoxCeleb1 test-set size (4874 utterances, 512-d): symmetry, diagonal = self-score formula, and
-    a sampled block against the oracle."""
+    a sampled block against the oracle.  4874 walks 64 x 64 tiles in both forms (780 tiles of 128 x 128 would fill the 512
+    block slots one and a half times: csrc/score.hip, gemm_nt); 5600 walks the 128 x 128 tiles in the dense form (990 of them: two
+    full rounds, K = 512) and 64 x 64 in the low-rank form (K = 200: the small tiles win whenever they pack as well) -- symmetric
+    walks all."""
     from xvector_amd import scoring
-    dim, n = 512, 4874
+    dim = 512
     mean, F, Sigma = po.make_plda(dim, 200, seed=21)
     x = _xvecs(n, dim, 5, mean)
     scorer = scoring.PldaScorer(mean, F, Sigma, lowrank=lowrank)
     s = scorer.score(x)
     assert s.shape == (n, n)
-    assert torch.equal(s, s.T)              # 780 of the 1521 tiles are computed, the rest are their mirror images
+    assert torch.equal(s, s.T)              # only tiles on or above the diagonal are computed, the rest are their mirror images
     phi, psi, cst = po.plda_constants(F, Sigma)
     xc = x - mean
     diag_ref = np.einsum("ij,ij->i", xc @ (phi + psi), xc) + cst
     assert _rel(torch.diagonal(s).cpu().numpy(), diag_ref) < 1e-9
-    rows, cols = slice(4800, 4874), slice(1000, 1100)
+    rows, cols = slice(n - 74, n), slice(1000, 1100)
     ref = po.fast_plda_scoring(x[rows], x[cols], mean, F, Sigma)
     assert _rel(s[rows, cols].cpu().numpy(), ref) < 1e-9
-    ref_d = po.fast_plda_scoring(x[4790:4874], x[4790:4874], mean, F, Sigma)        # a diagonal tile and its ragged edge
-    assert _rel(s[4790:, 4790:].cpu().numpy(), ref_d) < 1e-9
+    ref_d = po.fast_plda_scoring(x[n - 84:n], x[n - 84:n], mean, F, Sigma)          # a diagonal tile and its ragged edge
+    assert _rel(s[n - 84:, n - 84:].cpu().numpy(), ref_d) < 1e-9
     # the non-self path (full tile walk) is unchanged by the self path's shortcut
     two = scorer.score(x[:700], x[300:1500])
     assert _rel(two.cpu().numpy(), s[:700, 300:1500].cpu().numpy()) < 1e-12

@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/xvec_hip.h"
@@ -495,7 +496,12 @@ __global__ __launch_bounds__(256, 5) void mfcc512_kernel(const void* __restrict_
     const float* prow = ((row >> 1) & 1) ? smem + (row >> 2) * (2 * kEx + kExRow) + kExRow0 + (row & 1) * kPS
                                          : P0 + (2 * (row >> 2) + (row & 1)) * kPS;
     const int used = d.frame_len < 512 ? d.frame_len : 512;
-    const float scale = 0.25f / 512.f;                              // (1/2)^2 from the split, 1/nfft from powspec
+    // The power spectrum's factor 2^-11 ((1/2)^2 from the split, 1/nfft from powspec) costs no multiply per bin: 2^-6 rides in
+    // the second step's twiddles (the host's table; k1 = 0 has none: one packed multiply), which makes the squares 2^-12, and the
+    // 2 that is missing sits in the filterbank weights (host) and on the two frame energies -- powers of two all: exact
+    // rescalings, the results are the straight form's to the last bit or two (seven of nine test shapes bit for bit; the
+    // compiler's choice of fused multiply-adds differs).  -8 vector multiplies per pair, 39.19 -> 38.73 us interleaved.
+    constexpr float kTwoM6 = 0.015625f;
 
     // raw samples of a pair of frames (x[n] and x[n-1] of both).  Requesting them one pair ahead (during the split of
     // the previous pair / the previous tile's matrix products) measured the same, interleaved on one box, and would cost
@@ -579,8 +585,8 @@ __global__ __launch_bounds__(256, 5) void mfcc512_kernel(const void* __restrict_
                 ora |= __float_as_uint(x[a].x);
                 orb |= __float_as_uint(x[a].y);
             }
-            const float scale_a = __ballot((ora & 0x7fffffffu) != 0u) != 0ull ? scale : 0.f;
-            const float scale_b = __ballot((orb & 0x7fffffffu) != 0u) != 0ull ? scale : 0.f;
+            const bool live_a = __ballot((ora & 0x7fffffffu) != 0u) != 0ull, live_b = __ballot((orb & 0x7fffffffu) != 0u) != 0ull;
+            const bool mixed = live_a != live_b;                    // (uniform, rare) an all-zero frame packed with a live one
             // lane = 8b + c holds x[64a + 8b + c], a = 0..7
             dft8(x);                                                // over a -> k0
             twiddle<1>(x, w1);                                      // W_512^((8b + c) k0)
@@ -590,7 +596,8 @@ __global__ __launch_bounds__(256, 5) void mfcc512_kernel(const void* __restrict_
 #pragma unroll
             for (int b = 0; b < 8; ++b) x[b] = ex[hi * 72 + b * 8 + lo];   // lane = 8 k0 + c
             dft8(x);                                                // over b -> k1
-            twiddle<8>(x, w2 + lo);                                 // W_64^(c k1)
+            twiddle<8>(x, w2 + lo);                                 // 2^-6 W_64^(c k1)
+            x[0] = x[0] * kTwoM6;
 #pragma unroll
             for (int k1 = 0; k1 < 8; ++k1) ex[hi * 72 + k1 * 9 + lo] = x[k1];
             wave_lds_sync();
@@ -614,28 +621,39 @@ __global__ __launch_bounds__(256, 5) void mfcc512_kernel(const void* __restrict_
             // (second pair: into this wave's exchange region -- its last read of the region is in program order before these writes)
             float* pw = pp ? smem + wave * (2 * kEx + kExRow) + kExRow0 : P0 + 2 * wave * kPS;
             float ea = 0.f, eb = 0.f;
+            // (one uniform branch per pair, not one per bin: the mixed form is the rare one)
+            auto power_rows = [&](auto mixed_c) {
+                constexpr bool MIXED = decltype(mixed_c)::value;
 #pragma unroll
-            for (int k2 = 0; k2 < 4; ++k2) {
-                c32 z;           // Z[512 - k]: lane 0 pairs 64 k2 with 64 (8 - k2)
-                if (k2 == 0) { z.x = lane == 0 ? x[0].x : f[0].x; z.y = lane == 0 ? x[0].y : f[0].y; }
-                else { z.x = lane == 0 ? f[k2 - 1].x : f[k2].x; z.y = lane == 0 ? f[k2 - 1].y : f[k2].y; }
-                const c32 sa2 = cadd_conj(x[k2], z), sb2 = csub_conj(x[k2], z);   // 2A, 2iB
-                const c32 qa = sa2 * sa2, qb = sb2 * sb2;
-                const float pa = (qa.x + qa.y) * scale_a, pb = (qb.x + qb.y) * scale_b;
-                pw[bin0 + 64 * k2] = pa;
-                pw[kPS + bin0 + 64 * k2] = pb;
-                ea += pa;
-                eb += pb;
-            }
-            if (lane == 0) {     // bin 256 = Z[256] = lane 0's x[4], its own partner: A[256] = Re, B[256] = Im (energies only)
-                ea += (4.f * x[4].x * x[4].x) * scale_a;
-                eb += (4.f * x[4].y * x[4].y) * scale_b;
-            }
+                for (int k2 = 0; k2 < 4; ++k2) {
+                    c32 z;           // Z[512 - k]: lane 0 pairs 64 k2 with 64 (8 - k2)
+                    if (k2 == 0) { z.x = lane == 0 ? x[0].x : f[0].x; z.y = lane == 0 ? x[0].y : f[0].y; }
+                    else { z.x = lane == 0 ? f[k2 - 1].x : f[k2].x; z.y = lane == 0 ? f[k2 - 1].y : f[k2].y; }
+                    const c32 sa2 = cadd_conj(x[k2], z), sb2 = csub_conj(x[k2], z);   // 2A, 2iB
+                    const c32 qa = sa2 * sa2, qb = sb2 * sb2;
+                    float pa = qa.x + qa.y, pb = qb.x + qb.y;       // half the power (see kTwoM6)
+                    if constexpr (MIXED) {
+                        pa = live_a ? pa : 0.f;
+                        pb = live_b ? pb : 0.f;
+                    }
+                    pw[bin0 + 64 * k2] = pa;
+                    pw[kPS + bin0 + 64 * k2] = pb;
+                    ea += pa;
+                    eb += pb;
+                }
+                if (lane == 0) {     // bin 256 = Z[256] = lane 0's x[4], its own partner: A[256] = Re, B[256] = Im (energies only)
+                    const float ta = 4.f * x[4].x * x[4].x, tb = 4.f * x[4].y * x[4].y;
+                    ea += MIXED && !live_a ? 0.f : ta;
+                    eb += MIXED && !live_b ? 0.f : tb;
+                }
+            };
+            if (mixed) power_rows(std::true_type{});
+            else power_rows(std::false_type{});
             ea = wave_sum(ea);                                     // (vector-ALU cross-lane adds: __shfl_xor is six LDS round trips per value)
             eb = wave_sum(eb);
             if (lane == 0) {
-                en[par * kTile + r0] = ea == 0.f ? kEps : ea;
-                en[par * kTile + r0 + 1] = eb == 0.f ? kEps : eb;
+                en[par * kTile + r0] = ea == 0.f ? kEps : 2.f * ea;
+                en[par * kTile + r0 + 1] = eb == 0.f ? kEps : 2.f * eb;
             }
         }
         // the filterbank's B fragments: requested here, used behind the barrier (resident they were twenty registers of the 96
@@ -902,15 +920,15 @@ int xvec_mfcc_create(const xvec_mfcc_cfg* cfg, xvec_mfcc_plan** out) {
         f_tw2 = (int)blob.size();
         for (int k = 1; k < 8; ++k)
             for (int c = 0; c < 8; ++c) {
-                blob.push_back((float)std::cos(2.0 * M_PI * (c * k) / 64.0));
-                blob.push_back((float)(-std::sin(2.0 * M_PI * (c * k) / 64.0)));
+                blob.push_back((float)std::cos(2.0 * M_PI * (c * k) / 64.0) * 0.015625f);   // (x 2^-6: fft512, kTwoM6)
+                blob.push_back((float)(-std::sin(2.0 * M_PI * (c * k) / 64.0)) * 0.015625f);
             }
         // dense filterbank [32][256] (bin 256 never carries a weight: the last edge is exclusive) -> B fragments
         // of v_mfma_f32_16x16x4_f32: lane l of product (tile t, group g) holds FB[16t + (l & 15)][16g + 4(l >> 4) + j]
         std::vector<float> dense(32 * 256, 0.f);
         for (int j = 0; j < nfilt; ++j)
             for (int k = 0; k < off[j + 1] - off[j]; ++k)
-                if (lo[j] + k < 256) dense[j * 256 + lo[j] + k] = fbw[off[j] + k];
+                if (lo[j] + k < 256) dense[j * 256 + lo[j] + k] = 2.f * fbw[off[j] + k];   // (x 2: the kernel's power rows are halves, kTwoM6)
         f_fb = (int)blob.size();
         int g_lo[2] = {16, 16}, g_hi[2] = {0, 0};
         for (int t = 0; t < 2; ++t)

@@ -465,7 +465,9 @@ __global__ __launch_bounds__(256, 5) void mfcc512_kernel(const void* __restrict_
 #pragma unroll
     for (int k = 0; k < 7; ++k) w1[k] = reinterpret_cast<const c32*>(d.f_tw1)[k * 64 + lane];
     c32* w2 = reinterpret_cast<c32*>(en + 2 * kTile);
-    if (tid < 56) w2[tid] = reinterpret_cast<const c32*>(d.f_tw2)[tid];
+    if constexpr (!BAND) {                                          // (the banded form keeps its lane's seven in registers: w2r)
+        if (tid < 56) w2[tid] = reinterpret_cast<const c32*>(d.f_tw2)[tid];
+    }
     int* gat = reinterpret_cast<int*>(smem + kLdsFloats);           // BAND: [kBandGat][32] byte offsets
     if constexpr (BAND) gat[tid] = d.f_gat[tid];                    // kBandGat * 32 = 256 = the block's threads
     const __amdgpu_buffer_rsrc_t band_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(BAND ? d.f_band : d.f_fb), (short)0,
@@ -555,12 +557,13 @@ __global__ __launch_bounds__(256, 5) void mfcc512_kernel(const void* __restrict_
             }                                                                                                  \
         }                                                                                                      \
     }
-    // BAND leaves registers free (80 of the 96 that five waves per SIMD allow): the DCT's B fragments of waves 0 and 1 stay
-    // resident (-0.3 us).  (Two or four of the five weight fragments resident as well: 39.35 / 39.34 against 39.34 us, nothing.)
-    f32x4v db_res[2] = {};
+    // BAND leaves registers free (80 of the 96 that five waves per SIMD allow): the second step's twiddles of this lane stay in
+    // registers -- seven 8-byte LDS reads per pair less, 38.33 -> 37.59 us: at five waves per SIMD the LDS unit is what the waves
+    // queue on (a sixth wave made it 44 us, profiles/experiments/README.md).  (The DCT's fragments resident instead: -0.3 us.)
+    c32 w2r[7] = {};
     if constexpr (BAND) {
-        db_res[0] = reinterpret_cast<const f32x4v*>(d.f_dct)[((wave & 1) * 2 + 0) * 64 + lane];
-        db_res[1] = reinterpret_cast<const f32x4v*>(d.f_dct)[((wave & 1) * 2 + 1) * 64 + lane];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) w2r[k] = reinterpret_cast<const c32*>(d.f_tw2)[k * 8 + lo];
     }
     int par = 0;
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, par ^= 1) {
@@ -596,7 +599,8 @@ __global__ __launch_bounds__(256, 5) void mfcc512_kernel(const void* __restrict_
 #pragma unroll
             for (int b = 0; b < 8; ++b) x[b] = ex[hi * 72 + b * 8 + lo];   // lane = 8 k0 + c
             dft8(x);                                                // over b -> k1
-            twiddle<8>(x, w2 + lo);                                 // 2^-6 W_64^(c k1)
+            if constexpr (BAND) twiddle<1>(x, w2r);                 // 2^-6 W_64^(c k1), resident
+            else twiddle<8>(x, w2 + lo);
             x[0] = x[0] * kTwoM6;
 #pragma unroll
             for (int k1 = 0; k1 < 8; ++k1) ex[hi * 72 + k1 * 9 + lo] = x[k1];
@@ -753,9 +757,6 @@ __global__ __launch_bounds__(256, 5) void mfcc512_kernel(const void* __restrict_
                 db[0] = f32x4v{1.f, 0.5f, 0.25f, 2.f};
                 db[1] = db[0];
                 asm volatile("" : "+v"(db[0]), "+v"(db[1]));
-            } else if constexpr (BAND) {                            // (the banded form leaves the registers to keep them)
-                db[0] = db_res[0];
-                db[1] = db_res[1];
             } else {
                 db[0] = reinterpret_cast<const f32x4v*>(d.f_dct)[(wave * 2 + 0) * 64 + lane];
                 db[1] = reinterpret_cast<const f32x4v*>(d.f_dct)[(wave * 2 + 1) * 64 + lane];
